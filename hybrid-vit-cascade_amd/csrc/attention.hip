@@ -1,0 +1,680 @@
+// Fused multi-head attention for gfx950 (MI355X): forward, and a two-kernel backward.
+//
+// Replaces the reference's materialised-score attention
+//   models/vit_components.py:41-51   (self-attention : qkv split, q@k^T*scale, softmax, dropout, @v)
+//   models/vit_components.py:95-113  (cross-attention: q / kv split, same core)
+// with flash-style kernels that never write the (B,h,N,N) score matrix to HBM.
+//
+// Layout: q/k/v/o/do are addressed as  ptr[b*sb + n*sn + h*sh + d]  (d contiguous), so the
+// kernels read q,k,v straight out of the packed qkv / kv projection outputs and write o in
+// (B,N,h*d) order, which is what the reference's transpose(1,2).reshape produces.
+//
+// Work decomposition (all kernels: 256 threads = 4 waves, one wave per SIMD):
+//   fwd    : workgroup = 128 query rows of one (b,h); wave = 32 rows; loop over 64-key tiles
+//            staged in LDS (double buffered, register-staged global loads issued one tile ahead).
+//            S^T = K Q^T (key rows in registers, query on the lane) so max / sum / rescale are
+//            per-lane scalars; P feeds the PV product straight from the accumulators
+//            (accumulator-as-B-operand) and V is consumed through ds_read_b64_tr_b16.
+//   bwd dQ : same decomposition; recomputes S^T and dP^T = V dO^T, dQ += dS K (K via tr read).
+//   bwd dKV: workgroup = 128 keys of one (b,h); wave = 32 keys held in registers; loop over
+//            64-query tiles (Q, dO in LDS, read row-wise for S / dP and transposed for dV / dK).
+// The split backward recomputes S twice (7 products instead of 5) in exchange for having no
+// cross-workgroup reduction: dQ, dK, dV are bitwise reproducible.
+#include "hvc_common.hip.h"
+#include "hvc_kernels.h"
+
+namespace hvc {
+
+namespace {
+
+constexpr int kKT = 64;     // keys (or queries, in dKV) per LDS tile
+constexpr int kQB = 128;    // rows per workgroup
+
+template <typename T, int D>
+struct TileLoader {
+    static constexpr int NS = NSplit<T>::value;
+    static constexpr int CPR = D / 8;                  // 16-byte chunks per row
+    static constexpr int CHUNKS = kKT * CPR;           // per tile image
+    static constexpr int CPT = CHUNKS / 256;           // chunks per thread
+    Chunk8<T> reg[CPT];
+
+    __device__ __forceinline__ void issue(const T* base, int64_t sn, int row0, int nrows, bool vec, int tid) {
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) {
+            int c = tid + 256 * i;
+            int row = c / CPR, ch = c % CPR;
+            int n = row0 + row;
+            reg[i] = load_chunk<T>(base + (int64_t)n * sn + ch * 8, n < nrows ? 8 : 0, vec);
+        }
+    }
+    // images: NS consecutive tiles of kKT*D bf16
+    __device__ __forceinline__ void commit(bf16* images, int tid) {
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) {
+            int c = tid + 256 * i;
+            int row = c / CPR, ch = c % CPR;
+            bf16x8 im[NS];
+            chunk_split<T>(reg[i], im);
+#pragma unroll
+            for (int s = 0; s < NS; ++s) tile_store<D>(images + s * (kKT * D), row, ch, im[s]);
+        }
+    }
+};
+
+__device__ __forceinline__ void block_map(int id, int nbh, int nblk, int& bh, int& blk) {
+    // Workgroups b and b+8 share an XCD (round-robin dispatch): keep all blocks of one (b,h)
+    // on one XCD so its K/V (or Q/dO) stream is served by that XCD's L2.  Speed only.
+    if ((nbh & 7) == 0) {
+        int xcd = id & 7, slot = id >> 3;
+        bh = xcd + 8 * (slot / nblk);
+        blk = slot % nblk;
+    } else {
+        bh = id / nblk;
+        blk = id % nblk;
+    }
+}
+
+template <bool DROP>
+__device__ __forceinline__ void drop_pair(const AttnArgs& a, uint64_t rowbase, int key, float& x0, float& x1) {
+    if constexpr (DROP) {
+        uint64_t idx = rowbase + (uint64_t)(key >> 1);
+        uint32_t bits = rng_pair(a.seed_lo, a.seed_hi, (uint32_t)idx, (uint32_t)(idx >> 32));
+        x0 = ((bits & 0xffffu) >= a.drop_thresh) ? x0 * a.keep_scale : 0.f;
+        x1 = ((bits >> 16) >= a.drop_thresh) ? x1 * a.keep_scale : 0.f;
+    }
+}
+template <bool DROP>
+__device__ __forceinline__ bool drop_keep(const AttnArgs& a, uint64_t rowbase, int key) {
+    if constexpr (DROP) {
+        uint64_t idx = rowbase + (uint64_t)(key >> 1);
+        uint32_t bits = rng_pair(a.seed_lo, a.seed_hi, (uint32_t)idx, (uint32_t)(idx >> 32));
+        return ((bits >> (16 * (key & 1))) & 0xffffu) >= a.drop_thresh;
+    } else {
+        return true;
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------------
+template <typename T, int D, bool DROP>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
+    constexpr int NS = NSplit<T>::value;
+    constexpr int TILE = kKT * D;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16* lds = reinterpret_cast<bf16*>(smem);   // [buf][K|V][NS][TILE]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+
+    const int nqb = (a.Nq + kQB - 1) / kQB;
+    int bh, qb;
+    block_map(blockIdx.x, a.B * a.H, nqb, bh, qb);
+    const int b = bh / a.H, hh = bh % a.H;
+    const T* qp = reinterpret_cast<const T*>(a.q) + b * a.q_sb + hh * a.q_sh;
+    const T* kp = reinterpret_cast<const T*>(a.k) + b * a.k_sb + hh * a.k_sh;
+    const T* vp = reinterpret_cast<const T*>(a.v) + b * a.v_sb + hh * a.v_sh;
+    T* op = reinterpret_cast<T*>(a.o) + b * a.o_sb + hh * a.o_sh;
+    const bool vec = a.vec != 0;
+
+    const int q0 = qb * kQB + wave * 32;
+    const int qrow = q0 + r;
+    const bool qvalid = qrow < a.Nq;
+    const int qrow_c = qvalid ? qrow : a.Nq - 1;
+
+    bf16x8 qf[NS][D / 16];
+#pragma unroll
+    for (int s = 0; s < D / 16; ++s) {
+        Chunk8<T> c = load_chunk<T>(qp + (int64_t)qrow_c * a.q_sn + 16 * s + 8 * h, 8, vec);
+        bf16x8 im[NS];
+        chunk_split<T>(c, im);
+#pragma unroll
+        for (int x = 0; x < NS; ++x) qf[x][s] = im[x];
+    }
+
+    TileLoader<T, D> kl, vl;
+    auto Kt = [&](int buf) { return lds + (buf * 2 + 0) * NS * TILE; };
+    auto Vt = [&](int buf) { return lds + (buf * 2 + 1) * NS * TILE; };
+
+    const int nt = (a.Nk + kKT - 1) / kKT;
+    kl.issue(kp, a.k_sn, 0, a.Nk, vec, tid);
+    vl.issue(vp, a.v_sn, 0, a.Nk, vec, tid);
+    kl.commit(Kt(0), tid);
+    vl.commit(Vt(0), tid);
+    __syncthreads();
+
+    const float sl2 = a.scale * kLog2e;
+    float m = -INFINITY, l = 0.f;
+    f32x16 o[D / 32];
+#pragma unroll
+    for (int dt = 0; dt < D / 32; ++dt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[dt][i] = 0.f;
+
+    const uint64_t rowbase = ((uint64_t)bh * a.Nq + qrow_c) * (uint64_t)((a.Nk + 1) >> 1);
+
+    for (int t = 0; t < nt; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < nt) {
+            kl.issue(kp, a.k_sn, (t + 1) * kKT, a.Nk, vec, tid);
+            vl.issue(vp, a.v_sn, (t + 1) * kKT, a.Nk, vec, tid);
+        }
+        // S^T[key][q] = K Q^T
+        f32x16 st[2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) st[kt][i] = 0.f;
+#pragma unroll
+            for (int s = 0; s < D / 16; ++s) {
+#pragma unroll
+                for (int sa = 0; sa < NS; ++sa) {
+                    bf16x8 kf = row_frag<D>(Kt(buf) + sa * TILE, 32 * kt, 16 * s, lane);
+#pragma unroll
+                    for (int sb = 0; sb < NS; ++sb)
+                        if (sa + sb <= 1) st[kt] = mfma32(kf, qf[sb][s], st[kt]);
+                }
+            }
+        }
+        const int kbase = t * kKT;
+        if (kbase + kKT > a.Nk) {
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    if (kbase + 32 * kt + acc_row(i, h) >= a.Nk) st[kt][i] = -INFINITY;
+        }
+        float mloc = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) mloc = fmaxf(mloc, st[kt][i]);
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+        const float mnew = fmaxf(m, mloc);
+        const float alpha = __builtin_amdgcn_exp2f((m - mnew) * sl2);
+        const float msc = mnew * sl2;
+        float rs = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                float p = __builtin_amdgcn_exp2f(fmaf(st[kt][i], sl2, -msc));
+                rs += p;
+                st[kt][i] = p;
+            }
+        l = l * alpha + rs;
+        m = mnew;
+        if constexpr (DROP) {
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int i = 0; i < 16; i += 2) {
+                    float x0 = st[kt][i], x1 = st[kt][i + 1];
+                    drop_pair<DROP>(a, rowbase, kbase + 32 * kt + acc_row(i, h), x0, x1);
+                    st[kt][i] = x0; st[kt][i + 1] = x1;
+                }
+        }
+#pragma unroll
+        for (int dt = 0; dt < D / 32; ++dt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) o[dt][i] *= alpha;
+        // O^T[d][q] += V^T P^T
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                float x[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) x[j] = st[kt][8 * s2 + j];
+                bf16x8 pf[NS];
+                acc_split<NS>(x, pf);
+#pragma unroll
+                for (int dt = 0; dt < D / 32; ++dt) {
+#pragma unroll
+                    for (int sa = 0; sa < NS; ++sa) {
+                        bf16x8 vf = tr_frag<D, true>(Vt(buf) + sa * TILE, 32 * kt + 16 * s2, 32 * dt, lane);
+#pragma unroll
+                        for (int sb = 0; sb < NS; ++sb)
+                            if (sa + sb <= 1) o[dt] = mfma32(vf, pf[sb], o[dt]);
+                    }
+                }
+            }
+        }
+        if (t + 1 < nt) {
+            kl.commit(Kt(buf ^ 1), tid);
+            vl.commit(Vt(buf ^ 1), tid);
+        }
+        __syncthreads();
+    }
+
+    const float ltot = l + __shfl_xor(l, 32, 64);
+    const float inv = 1.f / ltot;
+    if (qvalid) {
+        T* orow = op + (int64_t)qrow * a.o_sn;
+#pragma unroll
+        for (int dt = 0; dt < D / 32; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int d0 = 32 * dt + 8 * g + 4 * h;
+                if constexpr (sizeof(T) == 2) {
+                    bf16x4 w;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) w[j] = f2bf(o[dt][4 * g + j] * inv);
+                    if (vec) *reinterpret_cast<bf16x4*>(orow + d0) = w;
+                    else { for (int j = 0; j < 4; ++j) orow[d0 + j] = w[j]; }
+                } else {
+                    f32x4 w;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) w[j] = o[dt][4 * g + j] * inv;
+                    if (vec) *reinterpret_cast<f32x4*>(orow + d0) = w;
+                    else { for (int j = 0; j < 4; ++j) orow[d0 + j] = w[j]; }
+                }
+            }
+        if (h == 0) a.lse[(int64_t)bh * a.Nq + qrow] = (m * sl2 + __builtin_amdgcn_logf(ltot)) * kLn2;
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// backward: delta[bh][q] = sum_d dO * O
+// ---------------------------------------------------------------------------------
+template <typename T, int D>
+__global__ __launch_bounds__(256) void attn_delta_kernel(const AttnArgs a) {
+    constexpr int LPR = D / 8;                      // lanes per row
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t row = gid / LPR;
+    const int part = (int)(gid % LPR);
+    const int64_t nrows = (int64_t)a.B * a.H * a.Nq;
+    float acc = 0.f;
+    if (row < nrows) {
+        const int q = (int)(row % a.Nq);
+        const int bh = (int)(row / a.Nq);
+        const int b = bh / a.H, hh = bh % a.H;
+        const T* op = reinterpret_cast<const T*>(a.o) + b * a.o_sb + hh * a.o_sh + (int64_t)q * a.o_sn + part * 8;
+        const T* dp = reinterpret_cast<const T*>(a.dout) + b * a.do_sb + hh * a.do_sh + (int64_t)q * a.do_sn + part * 8;
+        Chunk8<T> x = load_chunk<T>(op, 8, a.vec != 0);
+        Chunk8<T> y = load_chunk<T>(dp, 8, a.vec != 0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc += chunk_get<T>(x, j) * chunk_get<T>(y, j);
+    }
+#pragma unroll
+    for (int off = LPR / 2; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if (row < nrows && part == 0) a.delta[row] = acc;
+}
+
+// ---------------------------------------------------------------------------------
+// backward: dQ
+// ---------------------------------------------------------------------------------
+template <typename T, int D, bool DROP>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs a) {
+    constexpr int NS = NSplit<T>::value;
+    constexpr int TILE = kKT * D;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16* lds = reinterpret_cast<bf16*>(smem);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+
+    const int nqb = (a.Nq + kQB - 1) / kQB;
+    int bh, qb;
+    block_map(blockIdx.x, a.B * a.H, nqb, bh, qb);
+    const int b = bh / a.H, hh = bh % a.H;
+    const T* qp = reinterpret_cast<const T*>(a.q) + b * a.q_sb + hh * a.q_sh;
+    const T* kp = reinterpret_cast<const T*>(a.k) + b * a.k_sb + hh * a.k_sh;
+    const T* vp = reinterpret_cast<const T*>(a.v) + b * a.v_sb + hh * a.v_sh;
+    const T* dop = reinterpret_cast<const T*>(a.dout) + b * a.do_sb + hh * a.do_sh;
+    T* dqp = reinterpret_cast<T*>(a.dq) + b * a.dq_sb + hh * a.dq_sh;
+    const bool vec = a.vec != 0;
+
+    const int q0 = qb * kQB + wave * 32;
+    const int qrow = q0 + r;
+    const bool qvalid = qrow < a.Nq;
+    const int qrow_c = qvalid ? qrow : a.Nq - 1;
+
+    bf16x8 qf[NS][D / 16], dof[NS][D / 16];
+#pragma unroll
+    for (int s = 0; s < D / 16; ++s) {
+        bf16x8 im[NS];
+        chunk_split<T>(load_chunk<T>(qp + (int64_t)qrow_c * a.q_sn + 16 * s + 8 * h, 8, vec), im);
+#pragma unroll
+        for (int x = 0; x < NS; ++x) qf[x][s] = im[x];
+        chunk_split<T>(load_chunk<T>(dop + (int64_t)qrow_c * a.do_sn + 16 * s + 8 * h, 8, vec), im);
+#pragma unroll
+        for (int x = 0; x < NS; ++x) dof[x][s] = im[x];
+    }
+    const float lse2 = a.lse[(int64_t)bh * a.Nq + qrow_c] * kLog2e;
+    const float delta = a.delta[(int64_t)bh * a.Nq + qrow_c];
+
+    TileLoader<T, D> kl, vl;
+    auto Kt = [&](int buf) { return lds + (buf * 2 + 0) * NS * TILE; };
+    auto Vt = [&](int buf) { return lds + (buf * 2 + 1) * NS * TILE; };
+    const int nt = (a.Nk + kKT - 1) / kKT;
+    kl.issue(kp, a.k_sn, 0, a.Nk, vec, tid);
+    vl.issue(vp, a.v_sn, 0, a.Nk, vec, tid);
+    kl.commit(Kt(0), tid);
+    vl.commit(Vt(0), tid);
+    __syncthreads();
+
+    const float sl2 = a.scale * kLog2e;
+    f32x16 dq[D / 32];
+#pragma unroll
+    for (int dt = 0; dt < D / 32; ++dt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) dq[dt][i] = 0.f;
+    const uint64_t rowbase = ((uint64_t)bh * a.Nq + qrow_c) * (uint64_t)((a.Nk + 1) >> 1);
+
+    for (int t = 0; t < nt; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < nt) {
+            kl.issue(kp, a.k_sn, (t + 1) * kKT, a.Nk, vec, tid);
+            vl.issue(vp, a.v_sn, (t + 1) * kKT, a.Nk, vec, tid);
+        }
+        f32x16 st[2], dpt[2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { st[kt][i] = 0.f; dpt[kt][i] = 0.f; }
+#pragma unroll
+            for (int s = 0; s < D / 16; ++s) {
+#pragma unroll
+                for (int sa = 0; sa < NS; ++sa) {
+                    bf16x8 kf = row_frag<D>(Kt(buf) + sa * TILE, 32 * kt, 16 * s, lane);
+                    bf16x8 vf = row_frag<D>(Vt(buf) + sa * TILE, 32 * kt, 16 * s, lane);
+#pragma unroll
+                    for (int sb = 0; sb < NS; ++sb)
+                        if (sa + sb <= 1) {
+                            st[kt] = mfma32(kf, qf[sb][s], st[kt]);
+                            dpt[kt] = mfma32(vf, dof[sb][s], dpt[kt]);
+                        }
+                }
+            }
+        }
+        const int kbase = t * kKT;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int i = 0; i < 16; i += 2) {
+                const int key = kbase + 32 * kt + acc_row(i, h);
+                float p0 = __builtin_amdgcn_exp2f(fmaf(st[kt][i], sl2, -lse2));
+                float p1 = __builtin_amdgcn_exp2f(fmaf(st[kt][i + 1], sl2, -lse2));
+                if (key >= a.Nk) p0 = 0.f;
+                if (key + 1 >= a.Nk) p1 = 0.f;
+                float d0 = dpt[kt][i], d1 = dpt[kt][i + 1];
+                drop_pair<DROP>(a, rowbase, key, d0, d1);
+                st[kt][i] = p0 * (d0 - delta);
+                st[kt][i + 1] = p1 * (d1 - delta);
+            }
+        // dQ[q][d] += dS K  (dS^T accumulators as the A operand, K through the transposed read)
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                float x[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) x[j] = st[kt][8 * s2 + j];
+                bf16x8 dsf[NS];
+                acc_split<NS>(x, dsf);
+#pragma unroll
+                for (int dt = 0; dt < D / 32; ++dt) {
+#pragma unroll
+                    for (int sb = 0; sb < NS; ++sb) {
+                        bf16x8 kf = tr_frag<D, true>(Kt(buf) + sb * TILE, 32 * kt + 16 * s2, 32 * dt, lane);
+#pragma unroll
+                        for (int sa = 0; sa < NS; ++sa)
+                            if (sa + sb <= 1) dq[dt] = mfma32(dsf[sa], kf, dq[dt]);
+                    }
+                }
+            }
+        }
+        if (t + 1 < nt) {
+            kl.commit(Kt(buf ^ 1), tid);
+            vl.commit(Vt(buf ^ 1), tid);
+        }
+        __syncthreads();
+    }
+    // dq tile: rows = q (registers), col = d (lane)
+#pragma unroll
+    for (int dt = 0; dt < D / 32; ++dt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int qq = q0 + acc_row(i, h);
+            if (qq < a.Nq) dqp[(int64_t)qq * a.dq_sn + 32 * dt + r] = from_f<T>(dq[dt][i] * a.scale);
+        }
+}
+
+// ---------------------------------------------------------------------------------
+// backward: dK, dV
+// ---------------------------------------------------------------------------------
+template <typename T, int D, bool DROP>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs a) {
+    constexpr int NS = NSplit<T>::value;
+    constexpr int TILE = kKT * D;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16* lds = reinterpret_cast<bf16*>(smem);                       // [buf][Q|dO][NS][TILE]
+    float* stat = reinterpret_cast<float*>(lds + 4 * NS * TILE);     // [buf][lse2|delta][kKT]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+
+    const int nkb = (a.Nk + kQB - 1) / kQB;
+    int bh, kb;
+    block_map(blockIdx.x, a.B * a.H, nkb, bh, kb);
+    const int b = bh / a.H, hh = bh % a.H;
+    const T* qp = reinterpret_cast<const T*>(a.q) + b * a.q_sb + hh * a.q_sh;
+    const T* kp = reinterpret_cast<const T*>(a.k) + b * a.k_sb + hh * a.k_sh;
+    const T* vp = reinterpret_cast<const T*>(a.v) + b * a.v_sb + hh * a.v_sh;
+    const T* dop = reinterpret_cast<const T*>(a.dout) + b * a.do_sb + hh * a.do_sh;
+    T* dkp = reinterpret_cast<T*>(a.dk) + b * a.dk_sb + hh * a.dk_sh;
+    T* dvp = reinterpret_cast<T*>(a.dv) + b * a.dv_sb + hh * a.dv_sh;
+    const bool vec = a.vec != 0;
+
+    const int k0 = kb * kQB + wave * 32;
+    const int krow = k0 + r;
+    const bool kvalid = krow < a.Nk;
+
+    bf16x8 kf[NS][D / 16], vf[NS][D / 16];
+#pragma unroll
+    for (int s = 0; s < D / 16; ++s) {
+        bf16x8 im[NS];
+        chunk_split<T>(load_chunk<T>(kp + (int64_t)krow * a.k_sn + 16 * s + 8 * h, kvalid ? 8 : 0, vec), im);
+#pragma unroll
+        for (int x = 0; x < NS; ++x) kf[x][s] = im[x];
+        chunk_split<T>(load_chunk<T>(vp + (int64_t)krow * a.v_sn + 16 * s + 8 * h, kvalid ? 8 : 0, vec), im);
+#pragma unroll
+        for (int x = 0; x < NS; ++x) vf[x][s] = im[x];
+    }
+
+    TileLoader<T, D> ql, dl;
+    auto Qt = [&](int buf) { return lds + (buf * 2 + 0) * NS * TILE; };
+    auto Dt = [&](int buf) { return lds + (buf * 2 + 1) * NS * TILE; };
+    const int nt = (a.Nq + kKT - 1) / kKT;
+    float st_l = 0.f, st_d = 0.f;
+    auto issue_stat = [&](int t) {
+        if (tid < kKT) {
+            int q = t * kKT + tid;
+            st_l = q < a.Nq ? a.lse[(int64_t)bh * a.Nq + q] * kLog2e : INFINITY;
+            st_d = q < a.Nq ? a.delta[(int64_t)bh * a.Nq + q] : 0.f;
+        }
+    };
+    auto commit_stat = [&](int buf) {
+        if (tid < kKT) { stat[(buf * 2 + 0) * kKT + tid] = st_l; stat[(buf * 2 + 1) * kKT + tid] = st_d; }
+    };
+    ql.issue(qp, a.q_sn, 0, a.Nq, vec, tid);
+    dl.issue(dop, a.do_sn, 0, a.Nq, vec, tid);
+    issue_stat(0);
+    ql.commit(Qt(0), tid);
+    dl.commit(Dt(0), tid);
+    commit_stat(0);
+    __syncthreads();
+
+    const float sl2 = a.scale * kLog2e;
+    f32x16 dk[D / 32], dv[D / 32];
+#pragma unroll
+    for (int dt = 0; dt < D / 32; ++dt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { dk[dt][i] = 0.f; dv[dt][i] = 0.f; }
+    const uint64_t halfk = (uint64_t)((a.Nk + 1) >> 1);
+
+    for (int t = 0; t < nt; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < nt) {
+            ql.issue(qp, a.q_sn, (t + 1) * kKT, a.Nq, vec, tid);
+            dl.issue(dop, a.do_sn, (t + 1) * kKT, a.Nq, vec, tid);
+            issue_stat(t + 1);
+        }
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            // S[q][key] = Q K^T ; dP[q][key] = dO V^T   (key on the lane)
+            f32x16 s, dp;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
+#pragma unroll
+            for (int ks = 0; ks < D / 16; ++ks) {
+#pragma unroll
+                for (int sa = 0; sa < NS; ++sa) {
+                    bf16x8 qa = row_frag<D>(Qt(buf) + sa * TILE, 32 * qt, 16 * ks, lane);
+                    bf16x8 da = row_frag<D>(Dt(buf) + sa * TILE, 32 * qt, 16 * ks, lane);
+#pragma unroll
+                    for (int sb = 0; sb < NS; ++sb)
+                        if (sa + sb <= 1) {
+                            s = mfma32(qa, kf[sb][ks], s);
+                            dp = mfma32(da, vf[sb][ks], dp);
+                        }
+                }
+            }
+            float pd[16], ds[16];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 l4 = *reinterpret_cast<const f32x4*>(stat + (buf * 2 + 0) * kKT + 32 * qt + 8 * g + 4 * h);
+                const f32x4 d4 = *reinterpret_cast<const f32x4*>(stat + (buf * 2 + 1) * kKT + 32 * qt + 8 * g + 4 * h);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int i = 4 * g + j;
+                    float p = __builtin_amdgcn_exp2f(fmaf(s[i], sl2, -l4[j]));
+                    float dpv = dp[i];
+                    float pdv = p;
+                    if constexpr (DROP) {
+                        const int q = t * kKT + 32 * qt + 8 * g + 4 * h + j;
+                        const int qc = q < a.Nq ? q : a.Nq - 1;
+                        const uint64_t rowbase = ((uint64_t)bh * a.Nq + qc) * halfk;
+                        const bool keep = drop_keep<DROP>(a, rowbase, kvalid ? krow : 0);
+                        pdv = keep ? p * a.keep_scale : 0.f;
+                        dpv = keep ? dpv * a.keep_scale : 0.f;
+                    }
+                    pd[i] = pdv;
+                    ds[i] = p * (dpv - d4[j]);
+                }
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                float x[8], y[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { x[j] = pd[8 * s2 + j]; y[j] = ds[8 * s2 + j]; }
+                bf16x8 pf[NS], dsf[NS];
+                acc_split<NS>(x, pf);
+                acc_split<NS>(y, dsf);
+#pragma unroll
+                for (int dt = 0; dt < D / 32; ++dt) {
+#pragma unroll
+                    for (int sb = 0; sb < NS; ++sb) {
+                        bf16x8 dof = tr_frag<D, true>(Dt(buf) + sb * TILE, 32 * qt + 16 * s2, 32 * dt, lane);
+                        bf16x8 qf = tr_frag<D, true>(Qt(buf) + sb * TILE, 32 * qt + 16 * s2, 32 * dt, lane);
+#pragma unroll
+                        for (int sa = 0; sa < NS; ++sa)
+                            if (sa + sb <= 1) {
+                                dv[dt] = mfma32(pf[sa], dof, dv[dt]);
+                                dk[dt] = mfma32(dsf[sa], qf, dk[dt]);
+                            }
+                    }
+                }
+            }
+        }
+        if (t + 1 < nt) {
+            ql.commit(Qt(buf ^ 1), tid);
+            dl.commit(Dt(buf ^ 1), tid);
+            commit_stat(buf ^ 1);
+        }
+        __syncthreads();
+    }
+    // tiles: rows = key (registers), col = d (lane)
+#pragma unroll
+    for (int dt = 0; dt < D / 32; ++dt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int kk = k0 + acc_row(i, h);
+            if (kk < a.Nk) {
+                dkp[(int64_t)kk * a.dk_sn + 32 * dt + r] = from_f<T>(dk[dt][i] * a.scale);
+                dvp[(int64_t)kk * a.dv_sn + 32 * dt + r] = from_f<T>(dv[dt][i]);
+            }
+        }
+}
+
+template <typename T, int D>
+size_t fwd_lds_bytes() { return (size_t)2 * 2 * NSplit<T>::value * kKT * D * sizeof(bf16); }
+template <typename T, int D>
+size_t dkv_lds_bytes() { return fwd_lds_bytes<T, D>() + 2 * 2 * kKT * sizeof(float); }
+
+template <typename K>
+hipError_t set_lds(K kernel, size_t bytes) {
+    if (bytes > 48 * 1024)
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    return hipSuccess;
+}
+
+template <typename T, int D, bool DROP>
+hipError_t launch_fwd(const AttnArgs& a, hipStream_t st) {
+    const int nqb = (a.Nq + kQB - 1) / kQB;
+    const size_t lds = fwd_lds_bytes<T, D>();
+    auto k = attn_fwd_kernel<T, D, DROP>;
+    hipError_t e = set_lds(k, lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k, dim3(nqb * a.B * a.H), dim3(256), lds, st, a);
+    return hipGetLastError();
+}
+
+template <typename T, int D, bool DROP>
+hipError_t launch_bwd(const AttnArgs& a, hipStream_t st) {
+    {
+        const int64_t nthreads = (int64_t)a.B * a.H * a.Nq * (D / 8);
+        hipLaunchKernelGGL((attn_delta_kernel<T, D>), dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, st, a);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    {
+        const int nkb = (a.Nk + kQB - 1) / kQB;
+        const size_t lds = dkv_lds_bytes<T, D>();
+        auto k = attn_bwd_dkv_kernel<T, D, DROP>;
+        hipError_t e = set_lds(k, lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k, dim3(nkb * a.B * a.H), dim3(256), lds, st, a);
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    {
+        const int nqb = (a.Nq + kQB - 1) / kQB;
+        const size_t lds = fwd_lds_bytes<T, D>();
+        auto k = attn_bwd_dq_kernel<T, D, DROP>;
+        hipError_t e = set_lds(k, lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k, dim3(nqb * a.B * a.H), dim3(256), lds, st, a);
+        return hipGetLastError();
+    }
+}
+
+template <typename T>
+hipError_t dispatch(const AttnArgs& a, bool bwd, hipStream_t st) {
+    const bool drop = a.drop_thresh != 0;
+    if (a.D == 64) {
+        if (drop) return bwd ? launch_bwd<T, 64, true>(a, st) : launch_fwd<T, 64, true>(a, st);
+        return bwd ? launch_bwd<T, 64, false>(a, st) : launch_fwd<T, 64, false>(a, st);
+    }
+    if (a.D == 32) {
+        if (drop) return bwd ? launch_bwd<T, 32, true>(a, st) : launch_fwd<T, 32, true>(a, st);
+        return bwd ? launch_bwd<T, 32, false>(a, st) : launch_fwd<T, 32, false>(a, st);
+    }
+    return hipErrorInvalidValue;
+}
+
+}  // namespace
+
+hipError_t attention_launch(const AttnArgs& a, bool bwd, hipStream_t st) {
+    return a.is_bf16 ? dispatch<bf16>(a, bwd, st) : dispatch<float>(a, bwd, st);
+}
+
+}  // namespace hvc

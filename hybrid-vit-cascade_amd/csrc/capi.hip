@@ -1,0 +1,252 @@
+// extern "C" boundary of libhvc_hip.so: argument validation + translation into the launchers.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/hvc_hip.h"
+#include "hvc_kernels.h"
+
+namespace {
+
+thread_local char g_err[256] = "";
+
+int fail(int code, const char* msg) {
+    snprintf(g_err, sizeof(g_err), "%s", msg);
+    return code;
+}
+int hip_result(hipError_t e, const char* what) {
+    if (e == hipSuccess) return 0;
+    snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+    return (int)e;
+}
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+bool dtype_ok(int d) { return d == HVC_F32 || d == HVC_BF16; }
+
+uint32_t drop_threshold(float p) {
+    if (p <= 0.f) return 0;
+    double t = (double)p * 65536.0 + 0.5;
+    if (t < 1.0) t = 1.0;
+    if (t > 65535.0) t = 65535.0;
+    return (uint32_t)t;
+}
+
+}  // namespace
+
+extern "C" {
+
+int hvc_abi_version(void) { return HVC_ABI_VERSION; }
+const char* hvc_last_error(void) { return g_err; }
+
+int hvc_device_info(int* cu_count, int* wavefront, char* arch, int arch_len) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return hip_result(e, "hipGetDevice");
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, dev);
+    if (e != hipSuccess) return hip_result(e, "hipGetDeviceProperties");
+    if (cu_count) *cu_count = prop.multiProcessorCount;
+    if (wavefront) *wavefront = prop.warpSize;
+    if (arch && arch_len > 0) snprintf(arch, (size_t)arch_len, "%s", prop.gcnArchName);
+    return 0;
+}
+
+static int fill_attn(hvc::AttnArgs& a, const void* q, const void* k, const void* v, int B, int H, int Nq, int Nk, int D,
+                     int64_t q_sb, int64_t q_sn, int64_t q_sh, int64_t k_sb, int64_t k_sn, int64_t k_sh,
+                     int64_t v_sb, int64_t v_sn, int64_t v_sh, int64_t o_sb, int64_t o_sn, int64_t o_sh,
+                     float scale, float p_drop, uint64_t seed, int dtype) {
+    if (!q || !k || !v) return fail(HVC_E_BADARG, "attention: null operand");
+    if (B < 1 || H < 1 || Nq < 1 || Nk < 1) return fail(HVC_E_BADARG, "attention: empty dimension");
+    if (D != 32 && D != 64) return fail(HVC_E_UNSUPPORTED, "attention: head dim must be 32 or 64");
+    if (!dtype_ok(dtype)) return fail(HVC_E_BADARG, "attention: bad dtype");
+    if (!(scale > 0.f) || !(p_drop >= 0.f) || !(p_drop < 1.f)) return fail(HVC_E_BADARG, "attention: scale must be > 0 and 0 <= p_drop < 1");
+    memset(&a, 0, sizeof(a));
+    a.q = q; a.k = k; a.v = v;
+    a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.D = D;
+    a.q_sb = q_sb; a.q_sn = q_sn; a.q_sh = q_sh;
+    a.k_sb = k_sb; a.k_sn = k_sn; a.k_sh = k_sh;
+    a.v_sb = v_sb; a.v_sn = v_sn; a.v_sh = v_sh;
+    a.o_sb = o_sb; a.o_sn = o_sn; a.o_sh = o_sh;
+    a.do_sb = o_sb; a.do_sn = o_sn; a.do_sh = o_sh;
+    a.dq_sb = q_sb; a.dq_sn = q_sn; a.dq_sh = q_sh;
+    a.dk_sb = k_sb; a.dk_sn = k_sn; a.dk_sh = k_sh;
+    a.dv_sb = v_sb; a.dv_sn = v_sn; a.dv_sh = v_sh;
+    a.scale = scale;
+    a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32);
+    a.drop_thresh = drop_threshold(p_drop);
+    a.keep_scale = 1.f / (1.f - p_drop);
+    a.is_bf16 = dtype == HVC_BF16;
+    const int64_t strides[] = {q_sb, q_sn, q_sh, k_sb, k_sn, k_sh, v_sb, v_sn, v_sh, o_sb, o_sn, o_sh};
+    bool vec = true;
+    for (int64_t s : strides) vec = vec && (s % 8 == 0);
+    a.vec = vec;
+    return 0;
+}
+
+int hvc_attention_fwd(const void* q, const void* k, const void* v, void* o, float* lse,
+                      int B, int H, int Nq, int Nk, int D,
+                      int64_t q_sb, int64_t q_sn, int64_t q_sh, int64_t k_sb, int64_t k_sn, int64_t k_sh,
+                      int64_t v_sb, int64_t v_sn, int64_t v_sh, int64_t o_sb, int64_t o_sn, int64_t o_sh,
+                      float scale, float p_drop, uint64_t seed, int dtype, void* stream) {
+    hvc::AttnArgs a;
+    int rc = fill_attn(a, q, k, v, B, H, Nq, Nk, D, q_sb, q_sn, q_sh, k_sb, k_sn, k_sh, v_sb, v_sn, v_sh, o_sb, o_sn, o_sh, scale, p_drop, seed, dtype);
+    if (rc) return rc;
+    if (!o || !lse) return fail(HVC_E_BADARG, "attention_fwd: null output");
+    a.o = o; a.lse = lse;
+    a.vec = a.vec && aligned16(q) && aligned16(k) && aligned16(v) && aligned16(o);
+    return hip_result(hvc::attention_launch(a, false, (hipStream_t)stream), "attention_fwd");
+}
+
+int hvc_attention_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout,
+                      const float* lse, float* delta_ws, void* dq, void* dk, void* dv,
+                      int B, int H, int Nq, int Nk, int D,
+                      int64_t q_sb, int64_t q_sn, int64_t q_sh, int64_t k_sb, int64_t k_sn, int64_t k_sh,
+                      int64_t v_sb, int64_t v_sn, int64_t v_sh, int64_t o_sb, int64_t o_sn, int64_t o_sh,
+                      float scale, float p_drop, uint64_t seed, int dtype, void* stream) {
+    hvc::AttnArgs a;
+    int rc = fill_attn(a, q, k, v, B, H, Nq, Nk, D, q_sb, q_sn, q_sh, k_sb, k_sn, k_sh, v_sb, v_sn, v_sh, o_sb, o_sn, o_sh, scale, p_drop, seed, dtype);
+    if (rc) return rc;
+    if (!o || !dout || !lse || !delta_ws || !dq || !dk || !dv) return fail(HVC_E_BADARG, "attention_bwd: null operand");
+    a.o = const_cast<void*>(o); a.dout = dout; a.lse = const_cast<float*>(lse); a.delta = delta_ws;
+    a.dq = dq; a.dk = dk; a.dv = dv;
+    a.vec = a.vec && aligned16(q) && aligned16(k) && aligned16(v) && aligned16(o) && aligned16(dout);
+    return hip_result(hvc::attention_launch(a, true, (hipStream_t)stream), "attention_bwd");
+}
+
+int hvc_gemm(const void* A, const void* B, void* C, int M, int N, int K,
+             int64_t lda, int64_t ldb, int64_t ldc, int a_kmajor, int b_kmajor, float alpha,
+             const float* bias, int act, void* aux, const float* gate, const float* residual, int64_t ldr,
+             int rows_per_batch, float p_drop, uint64_t seed, int in_dtype, int out_dtype, void* stream) {
+    if (!A || !B || !C) return fail(HVC_E_BADARG, "gemm: null operand");
+    if (M < 1 || N < 1 || K < 1) return fail(HVC_E_BADARG, "gemm: empty dimension");
+    if (!dtype_ok(in_dtype) || !dtype_ok(out_dtype)) return fail(HVC_E_BADARG, "gemm: bad dtype");
+    if (in_dtype == HVC_F32 && out_dtype == HVC_BF16) return fail(HVC_E_UNSUPPORTED, "gemm: f32 in / bf16 out not supported");
+    if (act < 0 || act > 2) return fail(HVC_E_BADARG, "gemm: bad act");
+    if (act == 2 && !aux) return fail(HVC_E_BADARG, "gemm: act=2 needs aux");
+    if (gate && rows_per_batch < 1) return fail(HVC_E_BADARG, "gemm: gate needs rows_per_batch");
+    if (!(p_drop >= 0.f) || !(p_drop < 1.f)) return fail(HVC_E_BADARG, "gemm: bad p_drop");
+    hvc::GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K;
+    g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.a_kmajor = a_kmajor != 0; g.b_kmajor = b_kmajor != 0;
+    g.alpha = alpha; g.bias = bias; g.act = act; g.aux = aux; g.gate = gate; g.residual = residual; g.ldr = ldr;
+    g.rows_per_batch = rows_per_batch > 0 ? rows_per_batch : M;
+    g.seed_lo = (uint32_t)seed; g.seed_hi = (uint32_t)(seed >> 32);
+    g.drop_thresh = drop_threshold(p_drop);
+    g.keep_scale = 1.f / (1.f - p_drop);
+    g.in_bf16 = in_dtype == HVC_BF16; g.out_bf16 = out_dtype == HVC_BF16;
+    g.vec_a = aligned16(A) && (lda % 8 == 0);
+    g.vec_b = aligned16(B) && (ldb % 8 == 0);
+    return hip_result(hvc::gemm_launch(g, (hipStream_t)stream), "gemm");
+}
+
+int hvc_layernorm_fwd(const float* x, const float* gamma, const float* beta, const float* scale, const float* shift,
+                      void* y, float* mean, float* rstd, int rows, int C, int rows_per_batch, float eps,
+                      int out_dtype, void* stream) {
+    if (!x || !gamma || !beta || !y || !mean || !rstd) return fail(HVC_E_BADARG, "layernorm_fwd: null operand");
+    if ((scale == nullptr) != (shift == nullptr)) return fail(HVC_E_BADARG, "layernorm_fwd: scale and shift go together");
+    if (rows < 1 || C < 1 || C > 1024) return fail(HVC_E_UNSUPPORTED, "layernorm: 1 <= C <= 1024");
+    if (rows_per_batch < 1 || rows % rows_per_batch) return fail(HVC_E_BADARG, "layernorm: rows must be a multiple of rows_per_batch");
+    if (!dtype_ok(out_dtype)) return fail(HVC_E_BADARG, "layernorm: bad dtype");
+    hvc::LnArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = x; a.gamma = gamma; a.beta = beta; a.scale = scale; a.shift = shift; a.y = y; a.mean = mean; a.rstd = rstd;
+    a.rows = rows; a.C = C; a.rows_per_batch = rows_per_batch; a.eps = eps; a.out_bf16 = out_dtype == HVC_BF16;
+    return hip_result(hvc::layernorm_fwd_launch(a, (hipStream_t)stream), "layernorm_fwd");
+}
+
+int64_t hvc_layernorm_bwd_workspace(int rows, int C, int rows_per_batch) {
+    if (rows < 1 || C < 1 || rows_per_batch < 1 || rows % rows_per_batch) return -1;
+    const int nbatch = rows / rows_per_batch;
+    return (int64_t)nbatch * hvc::layernorm_bwd_blocks_per_batch(rows_per_batch) * 4 * C;
+}
+
+int hvc_layernorm_bwd(const void* dy, const float* x, const float* gamma, const float* beta, const float* scale,
+                      const float* mean, const float* rstd, const float* dres, float* dx, float* dgamma, float* dbeta,
+                      float* dscale, float* dshift, float* workspace, int rows, int C, int rows_per_batch,
+                      int dy_dtype, void* stream) {
+    if (!dy || !x || !gamma || !beta || !mean || !rstd || !dx || !dgamma || !dbeta || !workspace)
+        return fail(HVC_E_BADARG, "layernorm_bwd: null operand");
+    if (scale && (!dscale || !dshift)) return fail(HVC_E_BADARG, "layernorm_bwd: dscale/dshift required with scale");
+    if (rows < 1 || C < 1 || C > 1024) return fail(HVC_E_UNSUPPORTED, "layernorm: 1 <= C <= 1024");
+    if (rows_per_batch < 1 || rows % rows_per_batch) return fail(HVC_E_BADARG, "layernorm: rows must be a multiple of rows_per_batch");
+    if (!dtype_ok(dy_dtype)) return fail(HVC_E_BADARG, "layernorm: bad dtype");
+    hvc::LnArgs a;
+    memset(&a, 0, sizeof(a));
+    a.dy = dy; a.x = x; a.gamma = gamma; a.beta = beta; a.scale = scale; a.mean = const_cast<float*>(mean);
+    a.rstd = const_cast<float*>(rstd); a.dres = dres; a.dx = dx; a.dgamma = dgamma; a.dbeta = dbeta;
+    a.dscale = scale ? dscale : nullptr; a.dshift = scale ? dshift : nullptr; a.partial = workspace;
+    a.rows = rows; a.C = C; a.rows_per_batch = rows_per_batch; a.out_bf16 = dy_dtype == HVC_BF16;
+    a.blocks_per_batch = hvc::layernorm_bwd_blocks_per_batch(rows_per_batch);
+    return hip_result(hvc::layernorm_bwd_launch(a, (hipStream_t)stream), "layernorm_bwd");
+}
+
+int64_t hvc_branch_bwd_workspace(int rows, int N, int rows_per_batch) {
+    if (rows < 1 || N < 1 || rows_per_batch < 1 || rows % rows_per_batch) return -1;
+    return (int64_t)(rows / rows_per_batch) * hvc::rowops_blocks(rows_per_batch) * 2 * N;
+}
+
+int hvc_branch_bwd(const float* dy, const void* z, const float* gate, void* dz, float* dgate, float* dbias,
+                   float* workspace, int rows, int N, int rows_per_batch, int out_dtype, void* stream) {
+    if (!dy || !dz || !workspace) return fail(HVC_E_BADARG, "branch_bwd: null operand");
+    if (dgate && !z) return fail(HVC_E_BADARG, "branch_bwd: dgate needs z");
+    if (rows < 1 || N < 1 || rows_per_batch < 1 || rows % rows_per_batch) return fail(HVC_E_BADARG, "branch_bwd: bad shape");
+    if (!dtype_ok(out_dtype)) return fail(HVC_E_BADARG, "branch_bwd: bad dtype");
+    hvc::BranchArgs a;
+    memset(&a, 0, sizeof(a));
+    a.dy = dy; a.z = z; a.gate = gate; a.dz = dz; a.partial = workspace; a.dgate = dgate; a.dbias = dbias;
+    a.rows = rows; a.N = N; a.rows_per_batch = rows_per_batch; a.blocks_per_batch = hvc::rowops_blocks(rows_per_batch);
+    a.out_bf16 = out_dtype == HVC_BF16;
+    return hip_result(hvc::branch_bwd_launch(a, (hipStream_t)stream), "branch_bwd");
+}
+
+int64_t hvc_colsum_workspace(int M, int N) {
+    if (M < 1 || N < 1) return -1;
+    return (int64_t)hvc::rowops_blocks(M) * N;
+}
+
+int hvc_colsum(const void* x, float* out, float* workspace, int M, int N, int dtype, void* stream) {
+    if (!x || !out || !workspace) return fail(HVC_E_BADARG, "colsum: null operand");
+    if (M < 1 || N < 1 || !dtype_ok(dtype)) return fail(HVC_E_BADARG, "colsum: bad shape/dtype");
+    return hip_result(hvc::colsum_launch(x, workspace, out, M, N, hvc::rowops_blocks(M), dtype == HVC_BF16, (hipStream_t)stream), "colsum");
+}
+
+int hvc_cast(const void* x, void* y, int64_t n, int in_dtype, int out_dtype, void* stream) {
+    if (!x || !y || n < 1) return fail(HVC_E_BADARG, "cast: bad operand");
+    if (!dtype_ok(in_dtype) || !dtype_ok(out_dtype) || in_dtype == out_dtype) return fail(HVC_E_BADARG, "cast: bad dtype pair");
+    return hip_result(hvc::cast_launch(x, y, n, in_dtype == HVC_BF16, out_dtype == HVC_BF16, (hipStream_t)stream), "cast");
+}
+
+static int fill_drr(hvc::DrrArgs& a, const void* vol, int B, int D, int H, int W, int axis, int exp_mode, float mu,
+                    float out_scale, float clamp_min, int transpose_out, int dtype) {
+    if (!vol) return fail(HVC_E_BADARG, "drr: null volume");
+    if (B < 1 || D < 1 || H < 1 || W < 1) return fail(HVC_E_BADARG, "drr: empty dimension");
+    if (axis != 0 && axis != 2) return fail(HVC_E_UNSUPPORTED, "drr: axis must be 0 (along D) or 2 (along W)");
+    if (!dtype_ok(dtype)) return fail(HVC_E_BADARG, "drr: bad dtype");
+    memset(&a, 0, sizeof(a));
+    a.vol = vol; a.B = B; a.D = D; a.H = H; a.W = W; a.axis = axis; a.exp_mode = exp_mode != 0; a.mu = mu;
+    a.out_scale = out_scale; a.clamp_min = clamp_min; a.transpose_out = (axis == 2) && transpose_out; a.is_bf16 = dtype == HVC_BF16;
+    return 0;
+}
+
+int hvc_drr_fwd(const void* vol, void* out, int B, int D, int H, int W, int axis, int exp_mode, float mu,
+                float out_scale, float clamp_min, int transpose_out, int dtype, void* stream) {
+    hvc::DrrArgs a;
+    int rc = fill_drr(a, vol, B, D, H, W, axis, exp_mode, mu, out_scale, clamp_min, transpose_out, dtype);
+    if (rc) return rc;
+    if (!out) return fail(HVC_E_BADARG, "drr_fwd: null output");
+    a.out = out;
+    return hip_result(hvc::drr_fwd_launch(a, (hipStream_t)stream), "drr_fwd");
+}
+
+int hvc_drr_bwd(const void* vol, const void* out, const void* dout, void* dvol, int B, int D, int H, int W, int axis,
+                int exp_mode, float mu, float out_scale, float clamp_min, int transpose_out, int dtype, void* stream) {
+    hvc::DrrArgs a;
+    int rc = fill_drr(a, vol, B, D, H, W, axis, exp_mode, mu, out_scale, clamp_min, transpose_out, dtype);
+    if (rc) return rc;
+    if (!out || !dout || !dvol) return fail(HVC_E_BADARG, "drr_bwd: null operand");
+    a.out = const_cast<void*>(out); a.dout = dout; a.dvol = dvol;
+    return hip_result(hvc::drr_bwd_launch(a, (hipStream_t)stream), "drr_bwd");
+}
+
+}  // extern "C"

@@ -1,0 +1,223 @@
+// Tiled MFMA GEMM with fused epilogues for gfx950:   C = residual + gate * drop(act(alpha * A B^T + bias))
+//
+// Covers every dense projection of the reference's ViT block and their gradients:
+//   models/vit_components.py:26,28,74,75,77   qkv / q / kv / proj Linear
+//   models/hybrid_vit_backbone.py:75-81       MLP Linear -> GELU(erf) -> Dropout -> Linear -> Dropout
+//   models/hybrid_vit_backbone.py:123,128,139 residual adds (gated by AdaLN gate_sa / gate_mlp)
+//   models/vit_components.py:131,144          AdaLN Linear(cond_dim, 6C)
+//
+// One kernel, four operand-layout variants:  C[i][j] = sum_k A(i,k) B(j,k)  where each operand is
+// either k-contiguous in memory (fetched from LDS with ds_read_b128 row fragments) or k-major
+// (its contraction index is the memory row index; fetched with ds_read_b64_tr_b16).  That gives
+//   y  = x W^T          (A k-contig, B k-contig)     forward Linear, W is [out][in]
+//   dx = dy W           (A k-contig, B k-major)      W read in place, no transposed copy
+//   dW = dy^T x         (A k-major,  B k-major)      activations read in place
+// Tile 128 x 128 x BK (BK = 64 for bf16 operands, 32 for fp32 operands carried as hi/lo bf16
+// images), 4 waves in a 2 x 2 grid, each wave 64 x 64 = 2 x 2 MFMA 32x32x16 tiles, LDS double
+// buffered with register-staged global loads issued one k-tile ahead.
+#include "hvc_common.hip.h"
+#include "hvc_kernels.h"
+
+namespace hvc {
+namespace {
+
+constexpr int kBM = 128, kBN = 128;
+
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+    return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+}
+
+// Operand tile loader.  KM = false: LDS image [128 rows][BK] (row = i, k contiguous);
+//                       KM = true : LDS image [BK rows][128] (row = k, i contiguous).
+template <typename T, int BK, bool KM>
+struct OperandTile {
+    static constexpr int NS = NSplit<T>::value;
+    static constexpr int CW = KM ? 128 : BK;
+    static constexpr int ROWS = KM ? BK : 128;
+    static constexpr int CPR = CW / 8;
+    static constexpr int CPT = ROWS * CPR / 256;
+    static constexpr int IMG = ROWS * CW;
+    Chunk8<T> reg[CPT];
+
+    // base: operand pointer; ld; i0: first row(i) of this tile; ni: extent of i; k0: first k; nk: extent of k
+    __device__ __forceinline__ void issue(const T* base, int64_t ld, int i0, int ni, int k0, int nk, bool vec, int tid) {
+#pragma unroll
+        for (int c = 0; c < CPT; ++c) {
+            int id = tid + 256 * c;
+            int row = id / CPR, ch = id % CPR;
+            if constexpr (!KM) {
+                int i = i0 + row, k = k0 + ch * 8;
+                int nv = (i < ni) ? (nk - k) : 0;
+                reg[c] = load_chunk<T>(base + (int64_t)i * ld + k, nv > 8 ? 8 : nv, vec);
+            } else {
+                int k = k0 + row, i = i0 + ch * 8;
+                int nv = (k < nk) ? (ni - i) : 0;
+                reg[c] = load_chunk<T>(base + (int64_t)k * ld + i, nv > 8 ? 8 : nv, vec);
+            }
+        }
+    }
+    __device__ __forceinline__ void commit(bf16* images, int tid) {
+#pragma unroll
+        for (int c = 0; c < CPT; ++c) {
+            int id = tid + 256 * c;
+            int row = id / CPR, ch = id % CPR;
+            bf16x8 im[NS];
+            chunk_split<T>(reg[c], im);
+#pragma unroll
+            for (int s = 0; s < NS; ++s) tile_store<CW>(images + s * IMG, row, ch, im[s]);
+        }
+    }
+    // fragment for the 32 rows(i) starting at r0 and k-step ks (16 wide)
+    static __device__ __forceinline__ bf16x8 frag(const bf16* image, int r0, int ks, int lane) {
+        if constexpr (!KM) return row_frag<CW>(image, r0, 16 * ks, lane);
+        else return tr_frag<CW, false>(image, 16 * ks, r0, lane);
+    }
+};
+
+template <typename TI, typename TO, bool AKM, bool BKM>
+__global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
+    constexpr int NS = NSplit<TI>::value;
+    constexpr int BK = sizeof(TI) == 2 ? 64 : 32;
+    using TA = OperandTile<TI, BK, AKM>;
+    using TB = OperandTile<TI, BK, BKM>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16* lds = reinterpret_cast<bf16*>(smem);
+    constexpr int A_SZ = NS * TA::IMG, B_SZ = NS * TB::IMG;
+    auto At = [&](int buf) { return lds + buf * (A_SZ + B_SZ); };
+    auto Bt = [&](int buf) { return lds + buf * (A_SZ + B_SZ) + A_SZ; };
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r = lane & 31, h = lane >> 5;
+
+    // XCD-aware tile order: workgroups that share an XCD (id % 8) walk neighbouring row panels
+    // of one column panel, so the B (weight) panel and A row panels stay in that XCD's L2.
+    const int tiles_m = (g.M + kBM - 1) / kBM, tiles_n = (g.N + kBN - 1) / kBN;
+    const int nwg = tiles_m * tiles_n;
+    int id = blockIdx.x;
+    {
+        const int q = nwg >> 3, rem = nwg & 7, xcd = id & 7, slot = id >> 3;
+        id = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + slot;
+    }
+    const int tm = id % tiles_m, tn = id / tiles_m;
+    const int i0 = tm * kBM, j0 = tn * kBN;
+
+    const TI* Ap = reinterpret_cast<const TI*>(g.A);
+    const TI* Bp = reinterpret_cast<const TI*>(g.B);
+    TA ta;
+    TB tb;
+    const int nkt = (g.K + BK - 1) / BK;
+    ta.issue(Ap, g.lda, i0, g.M, 0, g.K, g.vec_a != 0, tid);
+    tb.issue(Bp, g.ldb, j0, g.N, 0, g.K, g.vec_b != 0, tid);
+    ta.commit(At(0), tid);
+    tb.commit(Bt(0), tid);
+    __syncthreads();
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[mi][ni][i] = 0.f;
+
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nkt) {
+            ta.issue(Ap, g.lda, i0, g.M, (kt + 1) * BK, g.K, g.vec_a != 0, tid);
+            tb.issue(Bp, g.ldb, j0, g.N, (kt + 1) * BK, g.K, g.vec_b != 0, tid);
+        }
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            bf16x8 af[NS][2], bfr[NS][2];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) af[s][mi] = TA::frag(At(buf) + s * TA::IMG, 64 * wm + 32 * mi, ks, lane);
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) bfr[s][ni] = TB::frag(Bt(buf) + s * TB::IMG, 64 * wn + 32 * ni, ks, lane);
+            }
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                    for (int sa = 0; sa < NS; ++sa)
+#pragma unroll
+                        for (int sb = 0; sb < NS; ++sb)
+                            if (sa + sb <= 1) acc[mi][ni] = mfma32(af[sa][mi], bfr[sb][ni], acc[mi][ni]);
+        }
+        if (kt + 1 < nkt) {
+            ta.commit(At(buf ^ 1), tid);
+            tb.commit(Bt(buf ^ 1), tid);
+        }
+        __syncthreads();
+    }
+
+    // epilogue: rows in registers, columns on lanes -> each store instruction writes 32
+    // consecutive columns of one row.
+    TO* Cp = reinterpret_cast<TO*>(g.C);
+    TO* auxp = reinterpret_cast<TO*>(g.aux);
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        const int j = j0 + 64 * wn + 32 * ni + r;
+        if (j >= g.N) continue;
+        const float bj = g.bias ? g.bias[j] : 0.f;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+            for (int x = 0; x < 16; ++x) {
+                const int i = i0 + 64 * wm + 32 * mi + acc_row(x, h);
+                if (i >= g.M) continue;
+                float v = acc[mi][ni][x] * g.alpha + bj;
+                if (g.act == kActGelu) {
+                    if (auxp) auxp[(int64_t)i * g.ldc + j] = from_f<TO>(v);
+                    v = gelu_f(v);
+                } else if (g.act == kActGeluGrad) {
+                    v *= gelu_grad_f(to_f<TO>(auxp[(int64_t)i * g.ldc + j]));
+                }
+                if (g.drop_thresh) {
+                    const uint64_t e = (uint64_t)i * (uint64_t)g.N + (uint64_t)j;
+                    const uint32_t bits = rng_pair(g.seed_lo, g.seed_hi, (uint32_t)(e >> 1), (uint32_t)(e >> 33));
+                    const bool keep = ((bits >> (16 * (e & 1))) & 0xffffu) >= g.drop_thresh;
+                    v = keep ? v * g.keep_scale : 0.f;
+                }
+                if (g.gate) v *= g.gate[(int64_t)(i / g.rows_per_batch) * g.N + j];
+                if (g.residual) v += g.residual[(int64_t)i * g.ldr + j];
+                Cp[(int64_t)i * g.ldc + j] = from_f<TO>(v);
+            }
+        }
+    }
+}
+
+template <typename TI, typename TO, bool AKM, bool BKM>
+hipError_t launch(const GemmArgs& g, hipStream_t st) {
+    constexpr int NS = NSplit<TI>::value;
+    constexpr int BK = sizeof(TI) == 2 ? 64 : 32;
+    const size_t lds = (size_t)2 * 2 * NS * 128 * BK * sizeof(bf16);
+    auto k = gemm_kernel<TI, TO, AKM, BKM>;
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    const int tiles = ((g.M + kBM - 1) / kBM) * ((g.N + kBN - 1) / kBN);
+    hipLaunchKernelGGL(k, dim3(tiles), dim3(256), lds, st, g);
+    return hipGetLastError();
+}
+
+template <typename TI, typename TO>
+hipError_t launch_layout(const GemmArgs& g, hipStream_t st) {
+    if (g.a_kmajor) return g.b_kmajor ? launch<TI, TO, true, true>(g, st) : launch<TI, TO, true, false>(g, st);
+    return g.b_kmajor ? launch<TI, TO, false, true>(g, st) : launch<TI, TO, false, false>(g, st);
+}
+
+}  // namespace
+
+hipError_t gemm_launch(const GemmArgs& g, hipStream_t st) {
+    if (g.in_bf16) return g.out_bf16 ? launch_layout<bf16, bf16>(g, st) : launch_layout<bf16, float>(g, st);
+    if (g.out_bf16) return hipErrorInvalidValue;
+    return launch_layout<float, float>(g, st);
+}
+
+}  // namespace hvc

@@ -1,0 +1,201 @@
+// Device-side building blocks shared by every gfx950 kernel in this library.
+//
+// Everything here is written for CDNA4 only: 64-lane wavefronts,
+// v_mfma_f32_32x32x16_bf16, ds_read_b64_tr_b16, 160 KiB LDS per CU.
+//
+// Fragment conventions (MI355X, mfma_f32_32x32x16_bf16; lane l, r = l & 31, h = l >> 5):
+//   A operand : A[row r][k = 8h + j]      j = 0..7  (bf16x8)
+//   B operand : B[k = 8h + j][col r]      j = 0..7  (bf16x8)
+//   C/D       : C[row (i&3) + 8(i>>2) + 4h][col r]   i = 0..15 (f32x16)
+// so both operands are "8 consecutive k for my r", i.e. C[i][j] = sum_k A'[i][k] * B'[j][k]
+// with A', B' stored k-contiguous is the native form ("row fragment"); an operand whose
+// contraction index is its *row* index in memory is fetched with the hardware transposed
+// LDS read ("tr fragment").
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace hvc {
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+constexpr int kWave = 64;
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kLn2 = 0.6931471805599453f;
+
+// Number of bf16 images an operand of type T is carried in.  fp32 operands are split
+// into hi + lo bf16 parts and every product is evaluated as hi*hi + hi*lo + lo*hi
+// (relative error ~2^-16 per product, fp32 accumulate), so the "fp32 mode" of every
+// MFMA kernel runs through exactly the same tiles, fragments and schedules as bf16 mode.
+template <typename T> struct NSplit { static constexpr int value = 1; };
+template <> struct NSplit<float> { static constexpr int value = 2; };
+
+__device__ __forceinline__ float bf2f(bf16 x) { return (float)x; }
+__device__ __forceinline__ bf16 f2bf(float x) { return (bf16)x; }
+
+__device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+// Row index inside a 32x32 accumulator tile of register i for lane-half h.
+__device__ __forceinline__ int acc_row(int i, int h) { return (i & 3) + 8 * (i >> 2) + 4 * h; }
+
+// ---------------------------------------------------------------------------------
+// 8-element global loads that yield the bf16 image(s) of the operand.
+// ---------------------------------------------------------------------------------
+template <typename T> struct Chunk8;   // raw 8 elements as they sit in HBM
+template <> struct Chunk8<bf16> { bf16x8 v; };
+template <> struct Chunk8<float> { f32x4 a, b; };
+
+template <typename T>
+__device__ __forceinline__ Chunk8<T> zero_chunk() {
+    Chunk8<T> c;
+    if constexpr (sizeof(T) == 2) { c.v = bf16x8{0, 0, 0, 0, 0, 0, 0, 0}; }
+    else { c.a = f32x4{0, 0, 0, 0}; c.b = f32x4{0, 0, 0, 0}; }
+    return c;
+}
+
+// p must be 16-byte aligned when vec is true.
+template <typename T>
+__device__ __forceinline__ Chunk8<T> load_chunk(const T* p, int nvalid, bool vec) {
+    Chunk8<T> c = zero_chunk<T>();
+    if (nvalid <= 0) return c;
+    if (vec && nvalid >= 8) {
+        if constexpr (sizeof(T) == 2) { c.v = *reinterpret_cast<const bf16x8*>(p); }
+        else { c.a = *reinterpret_cast<const f32x4*>(p); c.b = *reinterpret_cast<const f32x4*>(p + 4); }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (j < nvalid) {
+                if constexpr (sizeof(T) == 2) c.v[j] = p[j];
+                else { if (j < 4) c.a[j] = p[j]; else c.b[j - 4] = p[j]; }
+            }
+        }
+    }
+    return c;
+}
+
+template <typename T>
+__device__ __forceinline__ float chunk_get(const Chunk8<T>& c, int j) {
+    if constexpr (sizeof(T) == 2) return bf2f(c.v[j]);
+    else return j < 4 ? c.a[j] : c.b[j - 4];
+}
+
+// hi / lo bf16 images of a chunk (lo only meaningful for fp32).
+template <typename T>
+__device__ __forceinline__ void chunk_split(const Chunk8<T>& c, bf16x8 (&out)[NSplit<T>::value]) {
+    if constexpr (sizeof(T) == 2) { out[0] = c.v; }
+    else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float x = j < 4 ? c.a[j] : c.b[j - 4];
+            bf16 hi = f2bf(x);
+            out[0][j] = hi;
+            out[1][j] = f2bf(x - bf2f(hi));
+        }
+    }
+}
+
+// hi / lo images of 8 accumulator values (used when a product's result feeds the next MFMA).
+template <int NS>
+__device__ __forceinline__ void acc_split(const float (&x)[8], bf16x8 (&out)[NS]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        bf16 hi = f2bf(x[j]);
+        out[0][j] = hi;
+        if constexpr (NS == 2) out[1][j] = f2bf(x[j] - bf2f(hi));
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// LDS tile image: R rows of CW bf16 (CW = 32 or 64 => 64 / 128-byte rows), 16-byte
+// chunks XOR-swizzled so that the 16 rows a ds_read_b128 lane group touches land on
+// 16 different 16-byte slots of the 256-byte bank row.
+// ---------------------------------------------------------------------------------
+template <int CW>
+__device__ __forceinline__ int tile_off(int row, int chunk) {   // offset in bf16 elements
+    constexpr int CPR = CW / 8;          // chunks per row (4 or 8)
+    constexpr int RPB = 16 / CPR;        // rows per 256-byte bank row (4 or 2)
+    int sw = chunk ^ ((row / RPB) & (CPR - 1));
+    return row * CW + sw * 8;
+}
+
+template <int CW>
+__device__ __forceinline__ void tile_store(bf16* tile, int row, int chunk, bf16x8 v) {
+    *reinterpret_cast<bf16x8*>(tile + tile_off<CW>(row, chunk)) = v;
+}
+
+// Row fragment: elements k0 + 8h .. k0 + 8h + 7 of row r0 + r (k0 multiple of 16).
+template <int CW>
+__device__ __forceinline__ bf16x8 row_frag(const bf16* tile, int r0, int k0, int lane) {
+    int r = r0 + (lane & 31), h = lane >> 5;
+    return *reinterpret_cast<const bf16x8*>(tile + tile_off<CW>(r, (k0 >> 3) + h));
+}
+
+__device__ __forceinline__ bf16x4 lds_tr4(const bf16* p) {
+    s16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (s16x4 __attribute__((address_space(3)))*)(p));
+    return __builtin_bit_cast(bf16x4, t);
+}
+
+// Transposed fragment of a row-major tile whose ROW index is the contraction index.
+// Lane (r, h) receives column c0 + r at rows  kbase + 4h*HS + {0..3}  and  the same + 8/4.
+//   PERM = true  : rows k0 + 4h + {0..3} and k0 + 8 + 4h + {0..3}  -- matches the k order of
+//                  an accumulator tile re-used as the other operand (registers 8s..8s+7).
+//   PERM = false : rows k0 + 8h + {0..7}                           -- natural k order.
+// ds_read_b64_tr_b16 semantics: within each group of 16 lanes, lane 4q+p supplies the address
+// of row q, columns 4p..4p+3 of a 4x16 block; lane i receives column i, rows 0..3.
+// Requires EXEC = all ones.
+template <int CW, bool PERM>
+__device__ __forceinline__ bf16x8 tr_frag(const bf16* tile, int k0, int c0, int lane) {
+    int g = lane >> 4, i = lane & 15, h = g >> 1;
+    int col = c0 + 16 * (g & 1) + 4 * (i & 3);
+    int rowa = k0 + (PERM ? 4 * h : 8 * h) + (i >> 2);
+    int rowb = rowa + (PERM ? 8 : 4);
+    const bf16* pa = tile + tile_off<CW>(rowa, col >> 3) + (col & 7);
+    const bf16* pb = tile + tile_off<CW>(rowb, col >> 3) + (col & 7);
+    bf16x4 lo = lds_tr4(pa);
+    bf16x4 hi = lds_tr4(pb);
+    return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+// ---------------------------------------------------------------------------------
+// Counter-based dropout RNG shared by forward and backward kernels.
+// keep(idx) is a pure function of (seed, 64-bit element index); 16-bit threshold.
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+// Returns 32 random bits for the pair-index idx (two 16-bit lots).
+__device__ __forceinline__ uint32_t rng_pair(uint32_t seed_lo, uint32_t seed_hi, uint32_t idx_lo, uint32_t idx_hi) {
+    return mix32(mix32(idx_lo ^ seed_lo) + (idx_hi ^ seed_hi) * 0x9E3779B9U);
+}
+
+// wave-level sum over all 64 lanes
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+template <typename T> __device__ __forceinline__ float to_f(T x);
+template <> __device__ __forceinline__ float to_f<float>(float x) { return x; }
+template <> __device__ __forceinline__ float to_f<bf16>(bf16 x) { return bf2f(x); }
+template <typename T> __device__ __forceinline__ T from_f(float x);
+template <> __device__ __forceinline__ float from_f<float>(float x) { return x; }
+template <> __device__ __forceinline__ bf16 from_f<bf16>(float x) { return f2bf(x); }
+
+}  // namespace hvc

@@ -1,0 +1,117 @@
+// Internal host-side argument blocks and launcher prototypes (one launcher per .hip file).
+// The public C ABI in include/hvc_hip.h is implemented on top of these in capi.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace hvc {
+
+struct AttnArgs {
+    const void *q, *k, *v;
+    void* o;
+    float* lse;          // [B*H][Nq], natural log
+    const void* dout;
+    float* delta;        // [B*H][Nq] workspace (bwd)
+    void *dq, *dk, *dv;
+    int B, H, Nq, Nk, D;
+    int64_t q_sb, q_sn, q_sh;
+    int64_t k_sb, k_sn, k_sh;
+    int64_t v_sb, v_sn, v_sh;
+    int64_t o_sb, o_sn, o_sh;
+    int64_t do_sb, do_sn, do_sh;
+    int64_t dq_sb, dq_sn, dq_sh;
+    int64_t dk_sb, dk_sn, dk_sh;
+    int64_t dv_sb, dv_sn, dv_sh;
+    float scale;
+    uint32_t seed_lo, seed_hi;
+    uint32_t drop_thresh;   // 0 = no dropout; element dropped when its 16-bit lot < thresh
+    float keep_scale;       // 1 / (1 - p)
+    int vec;                // 16-byte vector access legal for every operand
+    int is_bf16;
+};
+hipError_t attention_launch(const AttnArgs& a, bool bwd, hipStream_t st);
+
+enum GemmAct { kActNone = 0, kActGelu = 1, kActGeluGrad = 2 };
+
+struct GemmArgs {
+    const void* A;   // M x K   (k-contiguous: A[i*lda + k];  k-major: A[k*lda + i])
+    const void* B;   // N x K   (k-contiguous: B[j*ldb + k];  k-major: B[k*ldb + j])
+    void* C;         // M x N row-major, ldc
+    int M, N, K;
+    int64_t lda, ldb, ldc;
+    int a_kmajor, b_kmajor;
+    float alpha;
+    const float* bias;       // [N] or null
+    int act;                 // GemmAct
+    void* aux;               // act=gelu: optional pre-activation store; act=gelu_grad: pre-activation input (C dtype, ldc)
+    const float* gate;       // [M / rows_per_batch][N] or null
+    const float* residual;   // [M][N] fp32, ldr, or null
+    int64_t ldr;
+    int rows_per_batch;
+    uint32_t seed_lo, seed_hi, drop_thresh;
+    float keep_scale;
+    int in_bf16, out_bf16;
+    int vec_a, vec_b;
+};
+hipError_t gemm_launch(const GemmArgs& g, hipStream_t st);
+
+struct LnArgs {
+    const float* x;          // [rows][C] fp32 (residual stream)
+    const float* gamma;      // [C]
+    const float* beta;       // [C]
+    const float* scale;      // [rows / rows_per_batch][C] or null   (AdaLN: y = ln * (1 + scale) + shift)
+    const float* shift;
+    void* y;                 // [rows][C] out dtype
+    float* mean;             // [rows]
+    float* rstd;             // [rows]
+    const void* dy;          // bwd
+    const float* dres;       // bwd: optional fp32 gradient already flowing on the residual stream (added into dx)
+    float* dx;               // bwd: [rows][C] fp32
+    float* partial;          // bwd workspace: [nblk][4][C]  (dgamma, dbeta, dscale, dshift partials)
+    float* dgamma;           // [C]
+    float* dbeta;            // [C]
+    float* dscale;           // [nbatch][C] or null
+    float* dshift;
+    int rows, C, rows_per_batch;
+    float eps;
+    int out_bf16;
+    int blocks_per_batch;    // bwd partial layout
+};
+hipError_t layernorm_fwd_launch(const LnArgs& a, hipStream_t st);
+hipError_t layernorm_bwd_launch(const LnArgs& a, hipStream_t st);
+int layernorm_bwd_blocks_per_batch(int rows_per_batch);
+
+struct BranchArgs {
+    const float* dy;      // [rows][N] fp32 gradient on the residual stream
+    const void* z;        // [rows][N] branch output saved by the forward (needed for dgate) or null
+    const float* gate;    // [rows / rows_per_batch][N] or null
+    void* dz;             // [rows][N] out: gate * dy in the GEMM dtype
+    float* partial;       // workspace [nbatch * blocks_per_batch][2][N]
+    float* dgate;         // [nbatch][N] or null
+    float* dbias;         // [N] or null
+    int rows, N, rows_per_batch, blocks_per_batch;
+    int out_bf16;
+};
+hipError_t branch_bwd_launch(const BranchArgs& a, hipStream_t st);
+int rowops_blocks(int rows);
+hipError_t colsum_launch(const void* x, float* partial, float* out, int M, int N, int nblk, int is_bf16, hipStream_t st);
+hipError_t cast_launch(const void* x, void* y, int64_t n, int in_bf16, int out_bf16, hipStream_t st);
+
+struct DrrArgs {
+    const void* vol;    // [B][D][H][W]
+    void* out;          // axis 0: [B][H][W]; axis 2: [B][D][H] (or [B][H][D] when transpose_out)
+    const void* dout;   // bwd
+    void* dvol;         // bwd
+    int B, D, H, W;
+    int axis;           // 0 = project along D, 2 = project along W
+    int exp_mode;       // 1: Beer-Lambert exp(-mu (v + 1)), 0: plain intensity
+    float mu;
+    float out_scale;    // 1 for sum, 1/len for mean
+    float clamp_min;    // -inf for none
+    int transpose_out;
+    int is_bf16;
+};
+hipError_t drr_fwd_launch(const DrrArgs& a, hipStream_t st);
+hipError_t drr_bwd_launch(const DrrArgs& a, hipStream_t st);
+
+}  // namespace hvc

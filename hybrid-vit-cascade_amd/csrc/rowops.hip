@@ -1,0 +1,124 @@
+// Row-streaming helpers around the residual branches (HBM-bound, deterministic two-stage
+// column reductions):
+//   branch_bwd : backward of   x_out = x + gate_b * z     (models/hybrid_vit_backbone.py:123,128,139)
+//                dz = gate_b * dy (cast to the GEMM dtype), dgate_b = sum_rows dy * z,
+//                dbias = sum_rows dz   (the bias gradient of the Linear that produced z)
+//   colsum     : bias gradient of a Linear whose output gradient is already materialised.
+#include "hvc_common.hip.h"
+#include "hvc_kernels.h"
+
+namespace hvc {
+namespace {
+
+// grid = nbatch * bpb blocks; block = 256 threads, thread t owns columns t, t+256, ... (<= 4096 cols)
+template <typename TO>
+__global__ __launch_bounds__(256) void branch_bwd_kernel(const BranchArgs a) {
+    const int bpb = a.blocks_per_batch;
+    const int bidx = blockIdx.x / bpb, blk = blockIdx.x % bpb;
+    const int rpb = a.rows_per_batch;
+    const int per = (rpb + bpb - 1) / bpb;
+    const int r0 = blk * per, r1 = min(rpb, r0 + per);
+    const TO* z = reinterpret_cast<const TO*>(a.z);
+    TO* dz = reinterpret_cast<TO*>(a.dz);
+    for (int c = threadIdx.x; c < a.N; c += 256) {
+        const float gt = a.gate ? a.gate[(int64_t)bidx * a.N + c] : 1.f;
+        float sg = 0.f, sb = 0.f;
+        for (int rr = r0; rr < r1; ++rr) {
+            const int64_t e = ((int64_t)bidx * rpb + rr) * a.N + c;
+            const float d = a.dy[e];
+            const float v = d * gt;
+            if (z) sg += d * to_f<TO>(z[e]);
+            sb += v;
+            dz[e] = from_f<TO>(v);
+        }
+        a.partial[((size_t)blockIdx.x * 2 + 0) * a.N + c] = sg;
+        a.partial[((size_t)blockIdx.x * 2 + 1) * a.N + c] = sb;
+    }
+}
+
+__global__ __launch_bounds__(256) void branch_final_kernel(const BranchArgs a, int nbatch) {
+    const int N = a.N, bpb = a.blocks_per_batch;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < N) {
+        if (a.dbias) {
+            float s = 0.f;
+            for (int b = 0; b < nbatch * bpb; ++b) s += a.partial[((size_t)b * 2 + 1) * N + i];
+            a.dbias[i] = s;
+        }
+    } else if (a.dgate && i < N + nbatch * N) {
+        const int j = i - N, bidx = j / N, c = j % N;
+        float s = 0.f;
+        for (int b = 0; b < bpb; ++b) s += a.partial[((size_t)(bidx * bpb + b) * 2 + 0) * N + c];
+        a.dgate[(size_t)bidx * N + c] = s;
+    }
+}
+
+// grid.x = row blocks; thread t owns columns t, t+256...
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* x, float* partial, int M, int N, int nblk) {
+    const int per = (M + nblk - 1) / nblk;
+    const int r0 = blockIdx.x * per, r1 = min(M, r0 + per);
+    for (int c = threadIdx.x; c < N; c += 256) {
+        float s = 0.f;
+        for (int r = r0; r < r1; ++r) s += to_f<T>(x[(int64_t)r * N + c]);
+        partial[(size_t)blockIdx.x * N + c] = s;
+    }
+}
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* partial, float* out, int N, int nblk) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= N) return;
+    float s = 0.f;
+    for (int b = 0; b < nblk; ++b) s += partial[(size_t)b * N + c];
+    out[c] = s;
+}
+
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void cast_kernel(const TI* x, TO* y, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        y[i] = from_f<TO>(to_f<TI>(x[i]));
+}
+
+}  // namespace
+
+int rowops_blocks(int rows) {
+    int b = (rows + 31) / 32;
+    if (b > 512) b = 512;
+    if (b < 1) b = 1;
+    return b;
+}
+
+hipError_t branch_bwd_launch(const BranchArgs& a, hipStream_t st) {
+    if (a.rows % a.rows_per_batch != 0) return hipErrorInvalidValue;
+    const int nbatch = a.rows / a.rows_per_batch;
+    dim3 grid((unsigned)(nbatch * a.blocks_per_batch)), blk(256);
+    if (a.out_bf16) hipLaunchKernelGGL(branch_bwd_kernel<bf16>, grid, blk, 0, st, a);
+    else hipLaunchKernelGGL(branch_bwd_kernel<float>, grid, blk, 0, st, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    if (!a.dbias && !a.dgate) return hipSuccess;
+    const int n = a.N + (a.dgate ? nbatch * a.N : 0);
+    hipLaunchKernelGGL(branch_final_kernel, dim3((n + 255) / 256), blk, 0, st, a, nbatch);
+    return hipGetLastError();
+}
+
+hipError_t colsum_launch(const void* x, float* partial, float* out, int M, int N, int nblk, int is_bf16, hipStream_t st) {
+    if (is_bf16) hipLaunchKernelGGL(colsum_kernel<bf16>, dim3(nblk), dim3(256), 0, st, reinterpret_cast<const bf16*>(x), partial, M, N, nblk);
+    else hipLaunchKernelGGL(colsum_kernel<float>, dim3(nblk), dim3(256), 0, st, reinterpret_cast<const float*>(x), partial, M, N, nblk);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((N + 255) / 256), dim3(256), 0, st, partial, out, N, nblk);
+    return hipGetLastError();
+}
+
+hipError_t cast_launch(const void* x, void* y, int64_t n, int in_bf16, int out_bf16, hipStream_t st) {
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    dim3 grid((unsigned)blocks), blk(256);
+    if (!in_bf16 && out_bf16) hipLaunchKernelGGL((cast_kernel<float, bf16>), grid, blk, 0, st, reinterpret_cast<const float*>(x), reinterpret_cast<bf16*>(y), n);
+    else if (in_bf16 && !out_bf16) hipLaunchKernelGGL((cast_kernel<bf16, float>), grid, blk, 0, st, reinterpret_cast<const bf16*>(x), reinterpret_cast<float*>(y), n);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+}  // namespace hvc

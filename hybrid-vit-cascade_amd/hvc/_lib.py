@@ -1,0 +1,71 @@
+"""ctypes binding of libhvc_hip.so (the C ABI declared in include/hvc_hip.h).
+
+The library is the product path: there is no CPU or eager-PyTorch fallback.  Importing this
+module succeeds without a GPU (so the ABI can be inspected), but any compute call on a machine
+without the built library, or with non-HIP tensors, raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libhvc_hip.so")
+
+HVC_F32 = 0
+HVC_BF16 = 1
+ABI_VERSION = 1
+
+_i, _i64, _u64, _f, _p = C.c_int, C.c_int64, C.c_uint64, C.c_float, C.c_void_p
+
+# name -> (restype, argtypes); mirrors include/hvc_hip.h declaration by declaration.
+SIGNATURES = {
+    "hvc_abi_version": (_i, []),
+    "hvc_last_error": (C.c_char_p, []),
+    "hvc_device_info": (_i, [C.POINTER(_i), C.POINTER(_i), C.c_char_p, _i]),
+    "hvc_attention_fwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i] + [_i64] * 12 + [_f, _f, _u64, _i, _p]),
+    "hvc_attention_bwd": (_i, [_p] * 10 + [_i] * 5 + [_i64] * 12 + [_f, _f, _u64, _i, _p]),
+    "hvc_gemm": (_i, [_p, _p, _p, _i, _i, _i, _i64, _i64, _i64, _i, _i, _f, _p, _i, _p, _p, _p, _i64, _i,
+                      _f, _u64, _i, _i, _p]),
+    "hvc_layernorm_fwd": (_i, [_p] * 8 + [_i, _i, _i, _f, _i, _p]),
+    "hvc_layernorm_bwd_workspace": (_i64, [_i, _i, _i]),
+    "hvc_layernorm_bwd": (_i, [_p] * 14 + [_i, _i, _i, _i, _p]),
+    "hvc_branch_bwd_workspace": (_i64, [_i, _i, _i]),
+    "hvc_branch_bwd": (_i, [_p] * 7 + [_i, _i, _i, _i, _p]),
+    "hvc_colsum_workspace": (_i64, [_i, _i]),
+    "hvc_colsum": (_i, [_p, _p, _p, _i, _i, _i, _p]),
+    "hvc_cast": (_i, [_p, _p, _i64, _i, _i, _p]),
+    "hvc_drr_fwd": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _f, _f, _f, _i, _i, _p]),
+    "hvc_drr_bwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _f, _f, _i, _i, _p]),
+}
+
+_lib = None
+
+
+class HvcLibraryError(RuntimeError):
+    pass
+
+
+def load():
+    """Load (once) and return the ctypes handle; raises HvcLibraryError if the .so is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HvcLibraryError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C hybrid-vit-cascade_amd/csrc` (hipcc --offload-arch=gfx950). "
+            "There is no CPU fallback for the HVC ops.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError here = ABI mismatch, fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    if lib.hvc_abi_version() != ABI_VERSION:
+        raise HvcLibraryError(f"ABI version mismatch: library {lib.hvc_abi_version()} != binding {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().hvc_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"{what} failed (rc={rc}): {msg}")

@@ -1,0 +1,264 @@
+"""Thin tensor-level wrappers over the C ABI (no autograd here; see functional.py).
+
+Torch is used only as the owner of device memory and of the current HIP stream: every function
+checks its operands, allocates outputs with torch.empty and passes raw device pointers to
+libhvc_hip.so.  Non-HIP tensors are rejected -- there is no fallback path.
+"""
+import math
+
+import torch
+
+from . import _lib
+from ._lib import HVC_BF16, HVC_F32, check
+
+_DT = {torch.float32: HVC_F32, torch.bfloat16: HVC_BF16}
+
+
+def _code(dtype):
+    try:
+        return _DT[dtype]
+    except KeyError:
+        raise TypeError(f"HVC ops support float32 and bfloat16 tensors, got {dtype}") from None
+
+
+def _dev(*tensors):
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError("HVC ops run on the MI355X HIP path only: got a CPU tensor "
+                               "(there is no CPU fallback; use oracle/ for CPU checks)")
+    return tensors[0].device
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _f32c(t, name):
+    if t is None:
+        return None
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        raise ValueError(f"{name} must be a contiguous float32 tensor")
+    return t
+
+
+# --------------------------------------------------------------------------------------------
+# attention
+# --------------------------------------------------------------------------------------------
+def _bnhd_strides(t):
+    """t is a (B, N, H, D) view with unit stride in D -> (sb, sn, sh)."""
+    if t.dim() != 4 or t.stride(3) != 1:
+        raise ValueError("attention operands must be (B, N, H, D) views with contiguous head dim")
+    return t.stride(0), t.stride(1), t.stride(2)
+
+
+def attention_fwd(q, k, v, scale, p_drop=0.0, seed=0):
+    """q: (B,Nq,H,D), k/v: (B,Nk,H,D) views (any batch/token/head strides). Returns o (B,Nq,H,D), lse (B,H,Nq)."""
+    _dev(q, k, v)
+    B, Nq, H, D = q.shape
+    Nk = k.shape[1]
+    if k.shape != (B, Nk, H, D) or v.shape != (B, Nk, H, D) or not (q.dtype == k.dtype == v.dtype):
+        raise ValueError("attention: q/k/v shape or dtype mismatch")
+    o = torch.empty((B, Nq, H, D), dtype=q.dtype, device=q.device)
+    lse = torch.empty((B, H, Nq), dtype=torch.float32, device=q.device)
+    check(_lib.load().hvc_attention_fwd(
+        q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse.data_ptr(), B, H, Nq, Nk, D,
+        *_bnhd_strides(q), *_bnhd_strides(k), *_bnhd_strides(v), *_bnhd_strides(o),
+        float(scale), float(p_drop), int(seed), _code(q.dtype), _stream()), "hvc_attention_fwd")
+    return o, lse
+
+
+def attention_bwd(q, k, v, o, dout, lse, scale, p_drop=0.0, seed=0, dq=None, dk=None, dv=None):
+    """Gradients w.r.t. q, k, v.  dq/dk/dv may be preallocated views with the strides of q/k/v."""
+    _dev(q, k, v, o, dout, lse)
+    B, Nq, H, D = q.shape
+    Nk = k.shape[1]
+    if not o.is_contiguous():
+        raise ValueError("attention_bwd: o must be the contiguous (B,Nq,H,D) tensor returned by attention_fwd")
+    if dout.shape != o.shape or dout.dtype != o.dtype:
+        raise ValueError("attention_bwd: dout must match o")
+    dout = dout.contiguous()
+    if dq is None:
+        dq = torch.empty_strided(q.shape, q.stride(), dtype=q.dtype, device=q.device) if _dense_like(q) else torch.empty_like(q, memory_format=torch.contiguous_format)
+    if dk is None:
+        dk = torch.empty_strided(k.shape, k.stride(), dtype=k.dtype, device=k.device) if _dense_like(k) else torch.empty_like(k, memory_format=torch.contiguous_format)
+    if dv is None:
+        dv = torch.empty_strided(v.shape, v.stride(), dtype=v.dtype, device=v.device) if _dense_like(v) else torch.empty_like(v, memory_format=torch.contiguous_format)
+    # the ABI gives dq/dk/dv the strides of q/k/v
+    for g, x, n in ((dq, q, "dq"), (dk, k, "dk"), (dv, v, "dv")):
+        if g.shape != x.shape or any(gs != xs for gs, xs, sz in zip(g.stride(), x.stride(), x.shape) if sz > 1):
+            raise ValueError(f"attention_bwd: {n} must have the shape and strides of its primal")
+    delta = torch.empty((B, H, Nq), dtype=torch.float32, device=q.device)
+    check(_lib.load().hvc_attention_bwd(
+        q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), dout.data_ptr(), lse.data_ptr(),
+        delta.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), B, H, Nq, Nk, D,
+        *_bnhd_strides(q), *_bnhd_strides(k), *_bnhd_strides(v), *_bnhd_strides(o),
+        float(scale), float(p_drop), int(seed), _code(q.dtype), _stream()), "hvc_attention_bwd")
+    return dq, dk, dv
+
+
+def _dense_like(t):
+    return t.is_contiguous()
+
+
+# --------------------------------------------------------------------------------------------
+# gemm
+# --------------------------------------------------------------------------------------------
+ACT_NONE, ACT_GELU, ACT_GELU_GRAD = 0, 1, 2
+
+
+def gemm(a, b, *, a_kmajor=False, b_kmajor=False, alpha=1.0, bias=None, act=ACT_NONE, aux=None,
+         gate=None, residual=None, rows_per_batch=0, p_drop=0.0, seed=0, out_dtype=None, out=None):
+    """C[i][j] = sum_k A(i,k) B(j,k) with the fused epilogue of hvc_gemm.
+
+    a: (M,K) if not a_kmajor else (K,M);  b: (N,K) if not b_kmajor else (K,N); both 2-D with unit
+    inner stride.  Returns C (M,N)."""
+    _dev(a, b, bias, aux, gate, residual, out)
+    if a.dim() != 2 or b.dim() != 2 or a.stride(1) != 1 or b.stride(1) != 1:
+        raise ValueError("gemm operands must be 2-D with unit inner stride")
+    if a.dtype != b.dtype:
+        raise ValueError("gemm operands must share a dtype")
+    M, K = (a.shape[1], a.shape[0]) if a_kmajor else a.shape
+    N, Kb = (b.shape[1], b.shape[0]) if b_kmajor else b.shape
+    if K != Kb:
+        raise ValueError(f"gemm: contraction mismatch {K} vs {Kb}")
+    out_dtype = out_dtype or a.dtype
+    if out is None:
+        out = torch.empty((M, N), dtype=out_dtype, device=a.device)
+    elif out.shape != (M, N) or out.stride(1) != 1 or out.dtype != out_dtype:
+        raise ValueError("gemm: bad out tensor")
+    if aux is not None and (aux.shape != (M, N) or aux.dtype != out_dtype or aux.stride() != out.stride()):
+        raise ValueError("gemm: aux must match the output tensor")
+    _f32c(bias, "bias"), _f32c(gate, "gate")
+    if residual is not None and (residual.dtype != torch.float32 or residual.shape != (M, N) or residual.stride(1) != 1):
+        raise ValueError("gemm: residual must be fp32 (M,N)")
+    check(_lib.load().hvc_gemm(
+        a.data_ptr(), b.data_ptr(), out.data_ptr(), M, N, K, a.stride(0), b.stride(0), out.stride(0),
+        int(a_kmajor), int(b_kmajor), float(alpha), _ptr(bias), int(act), _ptr(aux), _ptr(gate),
+        _ptr(residual), residual.stride(0) if residual is not None else 0, int(rows_per_batch),
+        float(p_drop), int(seed), _code(a.dtype), _code(out_dtype), _stream()), "hvc_gemm")
+    return out
+
+
+# --------------------------------------------------------------------------------------------
+# layernorm
+# --------------------------------------------------------------------------------------------
+def layernorm_fwd(x, gamma, beta, scale=None, shift=None, *, rows_per_batch=None, eps=1e-5, out_dtype=torch.float32):
+    """x: (rows, C) fp32.  Returns y (rows, C) out_dtype, mean (rows,), rstd (rows,)."""
+    _dev(x, gamma, beta, scale, shift)
+    _f32c(x, "x"), _f32c(gamma, "gamma"), _f32c(beta, "beta"), _f32c(scale, "scale"), _f32c(shift, "shift")
+    rows, Cn = x.shape
+    rpb = rows_per_batch or rows
+    y = torch.empty((rows, Cn), dtype=out_dtype, device=x.device)
+    mean = torch.empty((rows,), dtype=torch.float32, device=x.device)
+    rstd = torch.empty((rows,), dtype=torch.float32, device=x.device)
+    check(_lib.load().hvc_layernorm_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _ptr(scale), _ptr(shift),
+                                        y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), rows, Cn, rpb, float(eps),
+                                        _code(out_dtype), _stream()), "hvc_layernorm_fwd")
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, gamma, beta, scale, mean, rstd, *, dres=None, rows_per_batch=None):
+    """Returns dx (fp32, includes dres), dgamma, dbeta, dscale, dshift (the last two None without scale)."""
+    _dev(dy, x, gamma, beta, scale, mean, rstd, dres)
+    rows, Cn = x.shape
+    rpb = rows_per_batch or rows
+    if not dy.is_contiguous() or dy.shape != x.shape:
+        raise ValueError("layernorm_bwd: dy must be contiguous (rows, C)")
+    _f32c(dres, "dres")
+    lib = _lib.load()
+    ws = torch.empty((lib.hvc_layernorm_bwd_workspace(rows, Cn, rpb),), dtype=torch.float32, device=x.device)
+    dx = torch.empty_like(x)
+    dgamma = torch.empty_like(gamma)
+    dbeta = torch.empty_like(beta)
+    dscale = torch.empty_like(scale) if scale is not None else None
+    dshift = torch.empty_like(scale) if scale is not None else None
+    check(lib.hvc_layernorm_bwd(dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _ptr(scale),
+                                mean.data_ptr(), rstd.data_ptr(), _ptr(dres), dx.data_ptr(), dgamma.data_ptr(),
+                                dbeta.data_ptr(), _ptr(dscale), _ptr(dshift), ws.data_ptr(), rows, Cn, rpb,
+                                _code(dy.dtype), _stream()), "hvc_layernorm_bwd")
+    return dx, dgamma, dbeta, dscale, dshift
+
+
+# --------------------------------------------------------------------------------------------
+# residual-branch backward, column sums, casts
+# --------------------------------------------------------------------------------------------
+def branch_bwd(dy, z=None, gate=None, *, rows_per_batch=None, out_dtype=torch.float32, want_bias=True):
+    """dy: (rows,N) fp32.  Returns dz (rows,N) out_dtype, dgate (nbatch,N) or None, dbias (N,) or None."""
+    _dev(dy, z, gate)
+    _f32c(dy, "dy"), _f32c(gate, "gate")
+    rows, N = dy.shape
+    rpb = rows_per_batch or rows
+    if z is not None and (z.shape != dy.shape or not z.is_contiguous() or z.dtype != out_dtype):
+        raise ValueError("branch_bwd: z must be contiguous (rows,N) in out_dtype")
+    lib = _lib.load()
+    ws = torch.empty((lib.hvc_branch_bwd_workspace(rows, N, rpb),), dtype=torch.float32, device=dy.device)
+    dz = torch.empty((rows, N), dtype=out_dtype, device=dy.device)
+    dgate = torch.empty((rows // rpb, N), dtype=torch.float32, device=dy.device) if (gate is not None and z is not None) else None
+    dbias = torch.empty((N,), dtype=torch.float32, device=dy.device) if want_bias else None
+    check(lib.hvc_branch_bwd(dy.data_ptr(), _ptr(z), _ptr(gate), dz.data_ptr(), _ptr(dgate), _ptr(dbias), ws.data_ptr(),
+                             rows, N, rpb, _code(out_dtype), _stream()), "hvc_branch_bwd")
+    return dz, dgate, dbias
+
+
+def colsum(x):
+    _dev(x)
+    if x.dim() != 2 or not x.is_contiguous():
+        raise ValueError("colsum: contiguous 2-D tensor expected")
+    M, N = x.shape
+    lib = _lib.load()
+    ws = torch.empty((lib.hvc_colsum_workspace(M, N),), dtype=torch.float32, device=x.device)
+    out = torch.empty((N,), dtype=torch.float32, device=x.device)
+    check(lib.hvc_colsum(x.data_ptr(), out.data_ptr(), ws.data_ptr(), M, N, _code(x.dtype), _stream()), "hvc_colsum")
+    return out
+
+
+def cast(x, dtype):
+    _dev(x)
+    if x.dtype == dtype:
+        return x
+    xc = x.contiguous()
+    y = torch.empty(xc.shape, dtype=dtype, device=x.device)
+    if xc.numel():
+        check(_lib.load().hvc_cast(xc.data_ptr(), y.data_ptr(), xc.numel(), _code(xc.dtype), _code(dtype), _stream()), "hvc_cast")
+    return y
+
+
+# --------------------------------------------------------------------------------------------
+# DRR
+# --------------------------------------------------------------------------------------------
+def drr_fwd(vol, axis, *, exp_mode, mu=0.3, out_scale=1.0, clamp_min=-math.inf, transpose_out=False):
+    """vol: (B,D,H,W) contiguous.  axis 0 -> (B,H,W); axis 2 -> (B,D,H) or (B,H,D) with transpose_out."""
+    _dev(vol)
+    if vol.dim() != 4 or not vol.is_contiguous():
+        raise ValueError("drr: contiguous (B,D,H,W) volume expected")
+    B, D, H, W = vol.shape
+    if axis == 0:
+        shape = (B, H, W)
+    elif axis == 2:
+        shape = (B, H, D) if transpose_out else (B, D, H)
+    else:
+        raise ValueError("drr: axis must be 0 or 2")
+    out = torch.empty(shape, dtype=vol.dtype, device=vol.device)
+    check(_lib.load().hvc_drr_fwd(vol.data_ptr(), out.data_ptr(), B, D, H, W, axis, int(exp_mode), float(mu),
+                                  float(out_scale), float(clamp_min), int(transpose_out), _code(vol.dtype), _stream()),
+          "hvc_drr_fwd")
+    return out
+
+
+def drr_bwd(vol, out, dout, axis, *, exp_mode, mu=0.3, out_scale=1.0, clamp_min=-math.inf, transpose_out=False):
+    _dev(vol, out, dout)
+    B, D, H, W = vol.shape
+    dout = dout.contiguous()
+    if dout.shape != out.shape or dout.dtype != vol.dtype:
+        raise ValueError("drr_bwd: dout must match the forward output")
+    dvol = torch.empty_like(vol)
+    check(_lib.load().hvc_drr_bwd(vol.data_ptr(), out.data_ptr(), dout.data_ptr(), dvol.data_ptr(), B, D, H, W, axis,
+                                  int(exp_mode), float(mu), float(out_scale), float(clamp_min), int(transpose_out),
+                                  _code(vol.dtype), _stream()), "hvc_drr_bwd")
+    return dvol

@@ -1,0 +1,157 @@
+/*
+ * hvc_hip.h -- C ABI of libhvc_hip.so: the MI355X (gfx950) native compute path behind the
+ * Hybrid-ViT-Cascade Python class surface.
+ *
+ * The reference (kanadm12/Hybrid-ViT-Cascade) has NO native / FFI layer: every entry point below
+ * replaces a sequence of stock ATen ops issued by the reference's Python modules.  Each declaration
+ * cites the reference lines whose arithmetic it replaces.  The host-side mirror of the reference's
+ * module surface (hybrid-vit-cascade_amd/models/...) binds these symbols with ctypes; see
+ * INTEGRATION.md for the stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers (HBM) unless stated; no torch types cross this boundary
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); every call is asynchronous
+ *     on that stream, allocates nothing and keeps no global state, so calls can be captured in
+ *     a hipGraph
+ *   - dtype codes: HVC_F32 = 0, HVC_BF16 = 1.  MFMA kernels compute HVC_F32 operands as split
+ *     bf16 (hi + lo) products with fp32 accumulation (~1e-5 relative), HVC_BF16 operands natively
+ *   - return value: 0 on success, a negative HVC_E_* code on a bad argument, a positive hipError_t
+ *     on a launch failure; hvc_last_error() returns a static message for the calling thread
+ *   - tensors are dense row-major with the strides stated per call (in ELEMENTS)
+ */
+#ifndef HVC_HIP_H
+#define HVC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HVC_F32 0
+#define HVC_BF16 1
+
+#define HVC_E_BADARG (-1)
+#define HVC_E_UNSUPPORTED (-2)
+
+#define HVC_ABI_VERSION 1
+
+/* Library / device probes (host side only, no kernel launch). */
+int hvc_abi_version(void);
+const char* hvc_last_error(void);
+/* Fills CU count and wavefront size of the current device and its gcnArchName; 0 on success. */
+int hvc_device_info(int* cu_count, int* wavefront, char* arch, int arch_len);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fused attention core.  Replaces models/vit_components.py:41-51 (MultiHeadSelfAttention.forward:
+ * reshape/permute of qkv, q@k^T*scale, softmax, attn_drop, @v, transpose/reshape) and
+ * models/vit_components.py:95-113 (MultiHeadCrossAttention.forward, same core with Nq != Nk).
+ *
+ * x[b][n][h][d] lives at  ptr[b*sb + n*sn + h*sh + d]  (head dim contiguous), so q/k/v can alias
+ * the packed projection output and `o` is written directly in the (B, N, h*d) layout.
+ * D must be 32 or 64.  lse is [B*H][Nq] fp32 (natural log of the softmax denominator).
+ * p_drop > 0 applies the attention-probability dropout of attn_drop with a counter-based RNG keyed
+ * by (seed, b, h, q, k): the backward call with the same seed regenerates the same mask.
+ * ---------------------------------------------------------------------------------------------- */
+int hvc_attention_fwd(const void* q, const void* k, const void* v, void* o, float* lse,
+                      int B, int H, int Nq, int Nk, int D,
+                      int64_t q_sb, int64_t q_sn, int64_t q_sh,
+                      int64_t k_sb, int64_t k_sn, int64_t k_sh,
+                      int64_t v_sb, int64_t v_sn, int64_t v_sh,
+                      int64_t o_sb, int64_t o_sn, int64_t o_sh,
+                      float scale, float p_drop, uint64_t seed, int dtype, void* stream);
+
+/* Gradient of the above (autograd of the same reference lines).  delta_ws: [B*H][Nq] fp32 scratch.
+ * dq/dk/dv use the strides of q/k/v respectively; dout uses the strides of o. */
+int hvc_attention_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout,
+                      const float* lse, float* delta_ws, void* dq, void* dk, void* dv,
+                      int B, int H, int Nq, int Nk, int D,
+                      int64_t q_sb, int64_t q_sn, int64_t q_sh,
+                      int64_t k_sb, int64_t k_sn, int64_t k_sh,
+                      int64_t v_sb, int64_t v_sn, int64_t v_sh,
+                      int64_t o_sb, int64_t o_sn, int64_t o_sh,
+                      float scale, float p_drop, uint64_t seed, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * GEMM with fused epilogue:   C = residual + gate_b * dropout(act(alpha * A B^T + bias))
+ *   C[i][j] = sum_k A(i,k) B(j,k);  an operand is k-contiguous (X[i*ld + k]) or, with *_kmajor = 1,
+ *   k-major (X[k*ld + i]) -- so dx = dy W and dW = dy^T x read W / activations in place.
+ * Replaces nn.Linear forward/backward at models/vit_components.py:26,28,41,54,74,75,77,95,98,115,
+ * 131,144 and models/hybrid_vit_backbone.py:75-81 (Linear, GELU(erf), Dropout, Linear, Dropout),
+ * plus the gated residual adds at models/hybrid_vit_backbone.py:123,128,139.
+ *   act: 0 none | 1 GELU(erf) (aux != NULL additionally receives the pre-activation, dtype/ld of C)
+ *        | 2 multiply by GELU'(aux)  (backward of 1; aux = saved pre-activation)
+ *   bias: [N] fp32 or NULL;  gate: [M / rows_per_batch][N] fp32 or NULL;
+ *   residual: [M][N] fp32 with leading dimension ldr, or NULL.
+ *   in_dtype / out_dtype: (BF16,BF16), (BF16,F32) or (F32,F32).
+ * ---------------------------------------------------------------------------------------------- */
+int hvc_gemm(const void* A, const void* B, void* C, int M, int N, int K,
+             int64_t lda, int64_t ldb, int64_t ldc, int a_kmajor, int b_kmajor, float alpha,
+             const float* bias, int act, void* aux,
+             const float* gate, const float* residual, int64_t ldr, int rows_per_batch,
+             float p_drop, uint64_t seed, int in_dtype, int out_dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * LayerNorm (+ optional AdaLN modulate y = ln(x) * (1 + scale_b) + shift_b).
+ * Replaces nn.LayerNorm at models/hybrid_vit_backbone.py:84-86,229 and the modulate lines
+ * models/hybrid_vit_backbone.py:120-121,136-137.  x: [rows][C] fp32, y: [rows][C] out_dtype,
+ * gamma/beta: [C] fp32, scale/shift: [rows / rows_per_batch][C] fp32 or both NULL. C <= 1024.
+ * mean / rstd: [rows] fp32 saved for the backward.
+ * ---------------------------------------------------------------------------------------------- */
+int hvc_layernorm_fwd(const float* x, const float* gamma, const float* beta,
+                      const float* scale, const float* shift, void* y, float* mean, float* rstd,
+                      int rows, int C, int rows_per_batch, float eps, int out_dtype, void* stream);
+
+/* Number of floats of scratch hvc_layernorm_bwd needs. */
+int64_t hvc_layernorm_bwd_workspace(int rows, int C, int rows_per_batch);
+
+/* dx = dres (optional, fp32, already on the residual stream) + LN backward;  dgamma/dbeta: [C];
+ * dscale/dshift: [rows / rows_per_batch][C] (required iff scale != NULL). */
+int hvc_layernorm_bwd(const void* dy, const float* x, const float* gamma, const float* beta,
+                      const float* scale, const float* mean, const float* rstd, const float* dres,
+                      float* dx, float* dgamma, float* dbeta, float* dscale, float* dshift,
+                      float* workspace, int rows, int C, int rows_per_batch, int dy_dtype,
+                      void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Backward of a (gated) residual branch  x_out = x + gate_b * z
+ * (models/hybrid_vit_backbone.py:123,128,139):  dz = gate_b * dy (cast to out_dtype),
+ * dgate_b[n] = sum_rows dy*z,  dbias[n] = sum_rows dz.  dy: [rows][N] fp32; z: [rows][N] out_dtype
+ * or NULL (then dgate must be NULL); gate NULL = ungated (cross-attention branch).
+ * ---------------------------------------------------------------------------------------------- */
+int64_t hvc_branch_bwd_workspace(int rows, int N, int rows_per_batch);
+int hvc_branch_bwd(const float* dy, const void* z, const float* gate, void* dz,
+                   float* dgate, float* dbias, float* workspace,
+                   int rows, int N, int rows_per_batch, int out_dtype, void* stream);
+
+/* Column sum of x[M][N] (bias gradient of a Linear, models/hybrid_vit_backbone.py:76).
+ * workspace: hvc_colsum_workspace(M, N) floats. */
+int64_t hvc_colsum_workspace(int M, int N);
+int hvc_colsum(const void* x, float* out, float* workspace, int M, int N, int dtype, void* stream);
+
+/* Elementwise dtype cast (fp32 <-> bf16) of n contiguous elements: parameter / activation casts
+ * that torch.autocast performs implicitly in the reference trainers
+ * (direct_regression/train_direct_4gpu.py:65). */
+int hvc_cast(const void* x, void* y, int64_t n, int in_dtype, int out_dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * DRR ray-sum projection.  vol: [B][D][H][W].
+ *   axis 0: out[b][h][w] = max(clamp_min, out_scale * sum_d f(vol))
+ *   axis 2: out[b][d][h] (or out[b][h][d] when transpose_out) = max(clamp_min, out_scale * sum_w f(vol))
+ *   f(v) = exp(-mu (v + 1)) when exp_mode else v.  Pass clamp_min = -INFINITY for no clamp.
+ * Replaces models/diagnostic_losses.py:45-63 (DRRRenderer.forward: exp_mode=1, mu=0.3, out_scale=1,
+ * clamp_min=1e-6, transpose_out=1 for angle 90) and
+ * direct_regression/progressive_cascade/loss_multiscale.py:260-267 (generate_drr: exp_mode=0,
+ * out_scale=1/D or 1/W, no clamp, no transpose).
+ * ---------------------------------------------------------------------------------------------- */
+int hvc_drr_fwd(const void* vol, void* out, int B, int D, int H, int W, int axis, int exp_mode,
+                float mu, float out_scale, float clamp_min, int transpose_out, int dtype,
+                void* stream);
+int hvc_drr_bwd(const void* vol, const void* out, const void* dout, void* dvol,
+                int B, int D, int H, int W, int axis, int exp_mode, float mu, float out_scale,
+                float clamp_min, int transpose_out, int dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HVC_HIP_H */
