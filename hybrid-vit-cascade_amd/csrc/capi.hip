@@ -115,8 +115,9 @@ int hvc_attention_bwd(const void* q, const void* k, const void* v, const void* o
 
 int hvc_gemm(const void* A, const void* B, void* C, int M, int N, int K,
              int64_t lda, int64_t ldb, int64_t ldc, int a_kmajor, int b_kmajor, float alpha,
-             const float* bias, int act, void* aux, const float* gate, const float* residual, int64_t ldr,
-             int rows_per_batch, float p_drop, uint64_t seed, int in_dtype, int out_dtype, void* stream) {
+             const float* bias, int act, void* aux, void* zsave, int64_t ldz, const float* gate,
+             const float* residual, int64_t ldr, int rows_per_batch, float p_drop, uint64_t seed,
+             int in_dtype, int out_dtype, void* stream) {
     if (!A || !B || !C) return fail(HVC_E_BADARG, "gemm: null operand");
     if (M < 1 || N < 1 || K < 1) return fail(HVC_E_BADARG, "gemm: empty dimension");
     if (!dtype_ok(in_dtype) || !dtype_ok(out_dtype)) return fail(HVC_E_BADARG, "gemm: bad dtype");
@@ -129,7 +130,7 @@ int hvc_gemm(const void* A, const void* B, void* C, int M, int N, int K,
     memset(&g, 0, sizeof(g));
     g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K;
     g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.a_kmajor = a_kmajor != 0; g.b_kmajor = b_kmajor != 0;
-    g.alpha = alpha; g.bias = bias; g.act = act; g.aux = aux; g.gate = gate; g.residual = residual; g.ldr = ldr;
+    g.alpha = alpha; g.bias = bias; g.act = act; g.aux = aux; g.zsave = zsave; g.ldz = ldz; g.gate = gate; g.residual = residual; g.ldr = ldr;
     g.rows_per_batch = rows_per_batch > 0 ? rows_per_batch : M;
     g.seed_lo = (uint32_t)seed; g.seed_hi = (uint32_t)(seed >> 32);
     g.drop_thresh = drop_threshold(p_drop);
@@ -187,7 +188,8 @@ int64_t hvc_branch_bwd_workspace(int rows, int N, int rows_per_batch) {
 }
 
 int hvc_branch_bwd(const float* dy, const void* z, const float* gate, void* dz, float* dgate, float* dbias,
-                   float* workspace, int rows, int N, int rows_per_batch, int out_dtype, void* stream) {
+                   float* workspace, int rows, int N, int rows_per_batch, float p_drop, uint64_t seed,
+                   int out_dtype, void* stream) {
     if (!dy || !dz || !workspace) return fail(HVC_E_BADARG, "branch_bwd: null operand");
     if (dgate && !z) return fail(HVC_E_BADARG, "branch_bwd: dgate needs z");
     if (rows < 1 || N < 1 || rows_per_batch < 1 || rows % rows_per_batch) return fail(HVC_E_BADARG, "branch_bwd: bad shape");
@@ -197,6 +199,9 @@ int hvc_branch_bwd(const float* dy, const void* z, const float* gate, void* dz, 
     a.dy = dy; a.z = z; a.gate = gate; a.dz = dz; a.partial = workspace; a.dgate = dgate; a.dbias = dbias;
     a.rows = rows; a.N = N; a.rows_per_batch = rows_per_batch; a.blocks_per_batch = hvc::rowops_blocks(rows_per_batch);
     a.out_bf16 = out_dtype == HVC_BF16;
+    if (!(p_drop >= 0.f) || !(p_drop < 1.f)) return fail(HVC_E_BADARG, "branch_bwd: bad p_drop");
+    a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32);
+    a.drop_thresh = drop_threshold(p_drop); a.keep_scale = 1.f / (1.f - p_drop);
     return hip_result(hvc::branch_bwd_launch(a, (hipStream_t)stream), "branch_bwd");
 }
 

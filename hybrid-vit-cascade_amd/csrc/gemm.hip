@@ -1,4 +1,4 @@
-// Tiled MFMA GEMM with fused epilogues for gfx950:   C = residual + gate * drop(act(alpha * A B^T + bias))
+// Tiled MFMA GEMM with fused epilogues for gfx950:   z = drop(act(alpha * A B^T + bias));  C = residual + gate * z
 //
 // Covers every dense projection of the reference's ViT block and their gradients:
 //   models/vit_components.py:26,28,74,75,77   qkv / q / kv / proj Linear
@@ -159,6 +159,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
     // consecutive columns of one row.
     TO* Cp = reinterpret_cast<TO*>(g.C);
     TO* auxp = reinterpret_cast<TO*>(g.aux);
+    TI* zp = reinterpret_cast<TI*>(g.zsave);
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
         const int j = j0 + 64 * wn + 32 * ni + r;
@@ -183,6 +184,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
                     const bool keep = ((bits >> (16 * (e & 1))) & 0xffffu) >= g.drop_thresh;
                     v = keep ? v * g.keep_scale : 0.f;
                 }
+                if (zp) zp[(int64_t)i * g.ldz + j] = from_f<TI>(v);
                 if (g.gate) v *= g.gate[(int64_t)(i / g.rows_per_batch) * g.N + j];
                 if (g.residual) v += g.residual[(int64_t)i * g.ldr + j];
                 Cp[(int64_t)i * g.ldc + j] = from_f<TO>(v);

@@ -44,6 +44,8 @@ struct GemmArgs {
     const float* bias;       // [N] or null
     int act;                 // GemmAct
     void* aux;               // act=gelu: optional pre-activation store; act=gelu_grad: pre-activation input (C dtype, ldc)
+    void* zsave;             // optional [M][N] (operand dtype, ldz): value before gate / residual (saved for dgate)
+    int64_t ldz;
     const float* gate;       // [M / rows_per_batch][N] or null
     const float* residual;   // [M][N] fp32, ldr, or null
     int64_t ldr;
@@ -91,6 +93,8 @@ struct BranchArgs {
     float* dbias;         // [N] or null
     int rows, N, rows_per_batch, blocks_per_batch;
     int out_bf16;
+    uint32_t seed_lo, seed_hi, drop_thresh;   // output dropout applied by the forward GEMM epilogue
+    float keep_scale;
 };
 hipError_t branch_bwd_launch(const BranchArgs& a, hipStream_t st);
 int rowops_blocks(int rows);

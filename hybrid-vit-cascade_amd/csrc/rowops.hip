@@ -1,7 +1,7 @@
 // Row-streaming helpers around the residual branches (HBM-bound, deterministic two-stage
 // column reductions):
 //   branch_bwd : backward of   x_out = x + gate_b * z     (models/hybrid_vit_backbone.py:123,128,139)
-//                dz = gate_b * dy (cast to the GEMM dtype), dgate_b = sum_rows dy * z,
+//                dz = gate_b * dy * dropmask (cast to the GEMM dtype), dgate_b = sum_rows dy * z,
 //                dbias = sum_rows dz   (the bias gradient of the Linear that produced z)
 //   colsum     : bias gradient of a Linear whose output gradient is already materialised.
 #include "hvc_common.hip.h"
@@ -26,7 +26,11 @@ __global__ __launch_bounds__(256) void branch_bwd_kernel(const BranchArgs a) {
         for (int rr = r0; rr < r1; ++rr) {
             const int64_t e = ((int64_t)bidx * rpb + rr) * a.N + c;
             const float d = a.dy[e];
-            const float v = d * gt;
+            float v = d * gt;
+            if (a.drop_thresh) {
+                const uint32_t bits = rng_pair(a.seed_lo, a.seed_hi, (uint32_t)((uint64_t)e >> 1), (uint32_t)((uint64_t)e >> 33));
+                v = (((bits >> (16 * (e & 1))) & 0xffffu) >= a.drop_thresh) ? v * a.keep_scale : 0.f;
+            }
             if (z) sg += d * to_f<TO>(z[e]);
             sb += v;
             dz[e] = from_f<TO>(v);

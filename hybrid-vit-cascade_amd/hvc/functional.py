@@ -1,0 +1,347 @@
+"""Autograd glue over the C-ABI kernels: one torch.autograd.Function per residual branch of the
+reference's HybridViTBlock3D (models/hybrid_vit_backbone.py:117-139), each running a fused HIP
+forward chain and a hand-ordered HIP backward chain, plus small general-purpose Functions used by
+the stand-alone module forwards.
+
+Precision: the residual stream and all parameters / gradients are fp32; branch interiors run in
+`cdt` (compute dtype): bfloat16 under torch.autocast (the reference trainers' mode,
+direct_regression/train_direct_4gpu.py:65) or float32 otherwise (split-bf16 MFMA, ~1e-5 rel).
+"""
+import warnings
+
+import torch
+
+from . import ops
+
+_warned_fp16 = False
+
+
+def compute_dtype(ref: torch.Tensor) -> torch.dtype:
+    """bf16 inside torch.autocast('cuda'), else fp32."""
+    global _warned_fp16
+    if torch.is_autocast_enabled():
+        dt = torch.get_autocast_dtype("cuda")
+        if dt == torch.float16 and not _warned_fp16:
+            warnings.warn("HVC kernels compute in bfloat16 on MI355X; autocast(float16) is mapped to bfloat16")
+            _warned_fp16 = True
+        return torch.bfloat16
+    return torch.float32
+
+
+# ---- weight casts are cached ON the parameter object, keyed by its version counter: parameters
+# change once per optimizer step, so the bf16 copies are refreshed once per step, not per use.
+_CAST_EPOCH = 0
+
+
+def invalidate_param_casts():
+    """Drop every cached low-precision weight copy (call after writing parameters through `.data`,
+    which does not bump the tensor version counter)."""
+    global _CAST_EPOCH
+    _CAST_EPOCH += 1
+
+
+def cast_param(p: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    if p.dtype == dtype:
+        d = p.detach()
+        return d if d.is_contiguous() else d.contiguous()
+    hit = getattr(p, "_hvc_cast", None)
+    ver = p._version
+    if hit is not None and hit[0] == (ver, _CAST_EPOCH, dtype):
+        return hit[1]
+    out = ops.cast(p.detach(), dtype)
+    try:
+        p._hvc_cast = ((ver, _CAST_EPOCH, dtype), out)
+    except AttributeError:
+        pass
+    return out
+
+
+def new_seed() -> int:
+    """Dropout seed drawn from torch's CPU generator (so torch.manual_seed / checkpoint replay apply)."""
+    return int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+
+
+def _f32(t):
+    return None if t is None else t.detach().float().contiguous()
+
+
+def _as_cdt(t, cdt):
+    t = t.detach()
+    if t.dtype != cdt:
+        return ops.cast(t, cdt)
+    return t.contiguous()
+
+
+# --------------------------------------------------------------------------------------------
+# generic pieces (stand-alone module forwards, AdaLN linear, context projection ...)
+# --------------------------------------------------------------------------------------------
+class LinearFn(torch.autograd.Function):
+    """y = x W^T + b on (M,K) x (N,K); x/W in cdt, y in out_dtype; grads for W, b in fp32."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, cdt, out_dtype, p_drop, seed):
+        xc = _as_cdt(x, cdt)
+        wc = cast_param(weight, cdt)
+        y = ops.gemm(xc, wc, bias=_f32(bias), out_dtype=out_dtype, p_drop=p_drop, seed=seed)
+        ctx.save_for_backward(xc, weight)
+        ctx.cfg = (cdt, x.dtype, bias is not None, p_drop, seed)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xc, weight = ctx.saved_tensors
+        cdt, xdt, has_bias, p_drop, seed = ctx.cfg
+        # branch_bwd = cast to cdt (+ output-dropout mask of the forward epilogue) + bias column sum
+        dyc, _, db = ops.branch_bwd(_f32(dy), None, None, out_dtype=cdt, want_bias=has_bias and ctx.needs_input_grad[2],
+                                    p_drop=p_drop, seed=seed)
+        wc = cast_param(weight, cdt)
+        dx = ops.gemm(dyc, wc, b_kmajor=True, out_dtype=torch.float32 if xdt == torch.float32 else cdt) if ctx.needs_input_grad[0] else None
+        dw = ops.gemm(dyc, xc, a_kmajor=True, b_kmajor=True, out_dtype=torch.float32) if ctx.needs_input_grad[1] else None
+        if dx is not None and dx.dtype != xdt:
+            dx = dx.to(xdt)
+        return dx, dw, db, None, None, None, None
+
+
+def linear(x, weight, bias=None, cdt=None, out_dtype=None, p_drop=0.0, seed=0):
+    """x: (..., K) -> (..., N); optional output dropout fused into the GEMM epilogue."""
+    cdt = cdt or compute_dtype(x)
+    out_dtype = out_dtype or cdt
+    shp = x.shape
+    y = LinearFn.apply(x.reshape(-1, shp[-1]), weight, bias, cdt, out_dtype, p_drop, seed)
+    return y.view(*shp[:-1], weight.shape[0])
+
+
+class LayerNormFn(torch.autograd.Function):
+    """LayerNorm (+ AdaLN modulate) of the fp32 residual stream, rows = B * N."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, scale, shift, rows_per_batch, out_dtype):
+        xf = _f32(x)
+        y, mean, rstd = ops.layernorm_fwd(xf, _f32(gamma), _f32(beta), _f32(scale), _f32(shift),
+                                          rows_per_batch=rows_per_batch, out_dtype=out_dtype)
+        ctx.save_for_backward(xf, gamma, beta, scale, mean, rstd)
+        ctx.rpb = rows_per_batch
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xf, gamma, beta, scale, mean, rstd = ctx.saved_tensors
+        dx, dg, db, dsc, dsh = ops.layernorm_bwd(dy.contiguous(), xf, _f32(gamma), _f32(beta), _f32(scale), mean, rstd,
+                                                 rows_per_batch=ctx.rpb)
+        return dx, dg, db, dsc, dsh, None, None
+
+
+def layer_norm(x, gamma, beta, scale=None, shift=None, out_dtype=torch.float32):
+    """x: (B,N,C) fp32; scale/shift: (B,1,C) or (B,C) or None."""
+    B, N, Cn = x.shape
+    if scale is not None:
+        scale, shift = scale.reshape(B, Cn), shift.reshape(B, Cn)
+    y = LayerNormFn.apply(x.reshape(B * N, Cn), gamma, beta, scale, shift, N, out_dtype)
+    return y.view(B, N, Cn)
+
+
+class PackedSelfAttnFn(torch.autograd.Function):
+    """Attention core on the packed projection qkv: (B, N, 3, H, D) -> o: (B, N, H*D)."""
+
+    @staticmethod
+    def forward(ctx, qkv, scale, p_drop, seed):
+        q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
+        o, lse = ops.attention_fwd(q, k, v, scale, p_drop, seed)
+        ctx.save_for_backward(qkv, o, lse)
+        ctx.cfg = (scale, p_drop, seed)
+        B, N, H, D = o.shape
+        return o.view(B, N, H * D)
+
+    @staticmethod
+    def backward(ctx, do):
+        qkv, o, lse = ctx.saved_tensors
+        scale, p_drop, seed = ctx.cfg
+        dqkv = torch.empty_like(qkv)
+        ops.attention_bwd(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], o, do.reshape(o.shape), lse, scale, p_drop, seed,
+                          dq=dqkv[:, :, 0], dk=dqkv[:, :, 1], dv=dqkv[:, :, 2])
+        return dqkv, None, None, None
+
+
+class PackedCrossAttnFn(torch.autograd.Function):
+    """q: (B, N, H, D), kv: (B, M, 2, H, D) -> o: (B, N, H*D)."""
+
+    @staticmethod
+    def forward(ctx, q, kv, scale, p_drop, seed):
+        o, lse = ops.attention_fwd(q, kv[:, :, 0], kv[:, :, 1], scale, p_drop, seed)
+        ctx.save_for_backward(q, kv, o, lse)
+        ctx.cfg = (scale, p_drop, seed)
+        B, N, H, D = o.shape
+        return o.view(B, N, H * D)
+
+    @staticmethod
+    def backward(ctx, do):
+        q, kv, o, lse = ctx.saved_tensors
+        scale, p_drop, seed = ctx.cfg
+        dq = torch.empty_like(q)
+        dkv = torch.empty_like(kv)
+        ops.attention_bwd(q, kv[:, :, 0], kv[:, :, 1], o, do.reshape(o.shape), lse, scale, p_drop, seed,
+                          dq=dq, dk=dkv[:, :, 0], dv=dkv[:, :, 1])
+        return dq, dkv, None, None, None
+
+
+# --------------------------------------------------------------------------------------------
+# fused residual branches of HybridViTBlock3D
+# --------------------------------------------------------------------------------------------
+def _mod2d(t, B, Cn):
+    return None if t is None else _f32(t.reshape(B, Cn))
+
+
+class SelfAttnBranchFn(torch.autograd.Function):
+    """x + gate * proj(attn(qkv((1 + scale) * LN(x) + shift)))   -- models/hybrid_vit_backbone.py:120-123."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, scale, shift, gate, w_qkv, w_proj, b_proj, heads, cdt, p_drop, seeds):
+        B, N, Cn = x.shape
+        D = Cn // heads
+        x2 = _f32(x).view(B * N, Cn)
+        sc, sh, gt = _mod2d(scale, B, Cn), _mod2d(shift, B, Cn), _mod2d(gate, B, Cn)
+        h, mean, rstd = ops.layernorm_fwd(x2, _f32(gamma), _f32(beta), sc, sh, rows_per_batch=N, out_dtype=cdt)
+        qkv = ops.gemm(h, cast_param(w_qkv, cdt)).view(B, N, 3, heads, D)
+        o, lse = ops.attention_fwd(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], D ** -0.5, p_drop, seeds[0])
+        o2 = o.view(B * N, Cn)
+        z = torch.empty((B * N, Cn), dtype=cdt, device=x.device) if gt is not None else None
+        out = ops.gemm(o2, cast_param(w_proj, cdt), bias=_f32(b_proj), zsave=z, gate=gt, residual=x2, rows_per_batch=N,
+                       p_drop=p_drop, seed=seeds[1], out_dtype=torch.float32)
+        ctx.save_for_backward(x2, gamma, beta, sc, gt, w_qkv, w_proj, h, mean, rstd, qkv, o, lse, z)
+        ctx.cfg = (B, N, Cn, heads, cdt, p_drop, seeds, scale is not None, gate is not None)
+        return out.view(B, N, Cn)
+
+    @staticmethod
+    def backward(ctx, dout):
+        x2, gamma, beta, sc, gt, w_qkv, w_proj, h, mean, rstd, qkv, o, lse, z = ctx.saved_tensors
+        B, N, Cn, heads, cdt, p_drop, seeds, has_mod, has_gate = ctx.cfg
+        D = Cn // heads
+        dy = _f32(dout).view(B * N, Cn)
+        dz, dgate, dbp = ops.branch_bwd(dy, z, gt, rows_per_batch=N, out_dtype=cdt, p_drop=p_drop, seed=seeds[1])
+        o2 = o.view(B * N, Cn)
+        dwp = ops.gemm(dz, o2, a_kmajor=True, b_kmajor=True, out_dtype=torch.float32)
+        do = ops.gemm(dz, cast_param(w_proj, cdt), b_kmajor=True)
+        dqkv = torch.empty_like(qkv)
+        ops.attention_bwd(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], o, do.view(o.shape), lse, D ** -0.5, p_drop, seeds[0],
+                          dq=dqkv[:, :, 0], dk=dqkv[:, :, 1], dv=dqkv[:, :, 2])
+        dqkv2 = dqkv.view(B * N, 3 * Cn)
+        dwqkv = ops.gemm(dqkv2, h, a_kmajor=True, b_kmajor=True, out_dtype=torch.float32)
+        dh = ops.gemm(dqkv2, cast_param(w_qkv, cdt), b_kmajor=True)
+        dx, dg, db, dsc, dsh = ops.layernorm_bwd(dh, x2, _f32(gamma), _f32(beta), sc, mean, rstd, dres=dy, rows_per_batch=N)
+        v3 = lambda t: None if t is None else t.view(B, 1, Cn)
+        return (dx.view(B, N, Cn), dg, db, v3(dsc) if has_mod else None, v3(dsh) if has_mod else None,
+                v3(dgate) if has_gate else None, dwqkv, dwp, dbp, None, None, None, None)
+
+
+class CrossAttnBranchFn(torch.autograd.Function):
+    """x + proj(attn(q(LN(x)), kv(context)))   -- models/hybrid_vit_backbone.py:126-128."""
+
+    @staticmethod
+    def forward(ctx, x, context, gamma, beta, w_q, w_kv, w_proj, b_proj, heads, cdt, p_drop, seeds):
+        B, N, Cn = x.shape
+        M, Cc = context.shape[1], context.shape[2]
+        D = Cn // heads
+        x2 = _f32(x).view(B * N, Cn)
+        c2 = _as_cdt(context, cdt).view(B * M, Cc)
+        h, mean, rstd = ops.layernorm_fwd(x2, _f32(gamma), _f32(beta), rows_per_batch=N, out_dtype=cdt)
+        q = ops.gemm(h, cast_param(w_q, cdt)).view(B, N, heads, D)
+        kv = ops.gemm(c2, cast_param(w_kv, cdt)).view(B, M, 2, heads, D)
+        o, lse = ops.attention_fwd(q, kv[:, :, 0], kv[:, :, 1], D ** -0.5, p_drop, seeds[0])
+        out = ops.gemm(o.view(B * N, Cn), cast_param(w_proj, cdt), bias=_f32(b_proj), residual=x2,
+                       p_drop=p_drop, seed=seeds[1], out_dtype=torch.float32)
+        ctx.save_for_backward(x2, c2, gamma, beta, w_q, w_kv, w_proj, h, mean, rstd, q, kv, o, lse)
+        ctx.cfg = (B, N, M, Cn, Cc, heads, cdt, p_drop, seeds, context.dtype)
+        return out.view(B, N, Cn)
+
+    @staticmethod
+    def backward(ctx, dout):
+        x2, c2, gamma, beta, w_q, w_kv, w_proj, h, mean, rstd, q, kv, o, lse = ctx.saved_tensors
+        B, N, M, Cn, Cc, heads, cdt, p_drop, seeds, ctx_dtype = ctx.cfg
+        D = Cn // heads
+        dy = _f32(dout).view(B * N, Cn)
+        dz, _, dbp = ops.branch_bwd(dy, None, None, rows_per_batch=N, out_dtype=cdt, p_drop=p_drop, seed=seeds[1])
+        dwp = ops.gemm(dz, o.view(B * N, Cn), a_kmajor=True, b_kmajor=True, out_dtype=torch.float32)
+        do = ops.gemm(dz, cast_param(w_proj, cdt), b_kmajor=True)
+        dq = torch.empty_like(q)
+        dkv = torch.empty_like(kv)
+        ops.attention_bwd(q, kv[:, :, 0], kv[:, :, 1], o, do.view(o.shape), lse, D ** -0.5, p_drop, seeds[0],
+                          dq=dq, dk=dkv[:, :, 0], dv=dkv[:, :, 1])
+        dq2, dkv2 = dq.view(B * N, Cn), dkv.view(B * M, 2 * Cn)
+        dwq = ops.gemm(dq2, h, a_kmajor=True, b_kmajor=True, out_dtype=torch.float32)
+        dh = ops.gemm(dq2, cast_param(w_q, cdt), b_kmajor=True)
+        dwkv = ops.gemm(dkv2, c2, a_kmajor=True, b_kmajor=True, out_dtype=torch.float32)
+        dctx = None
+        if ctx.needs_input_grad[1]:
+            dctx = ops.gemm(dkv2, cast_param(w_kv, cdt), b_kmajor=True, out_dtype=torch.float32).view(B, M, Cc)
+            if dctx.dtype != ctx_dtype:
+                dctx = dctx.to(ctx_dtype)
+        dx, dg, db, _, _ = ops.layernorm_bwd(dh, x2, _f32(gamma), _f32(beta), None, mean, rstd, dres=dy, rows_per_batch=N)
+        return dx.view(B, N, Cn), dctx, dg, db, dwq, dwkv, dwp, dbp, None, None, None, None
+
+
+class MlpBranchFn(torch.autograd.Function):
+    """x + gate * fc2(drop(gelu(fc1((1 + scale) * LN(x) + shift))))   -- models/hybrid_vit_backbone.py:136-139, :75-81."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, scale, shift, gate, w1, b1, w2, b2, cdt, p_drop, seeds):
+        B, N, Cn = x.shape
+        Hd = w1.shape[0]
+        x2 = _f32(x).view(B * N, Cn)
+        sc, sh, gt = _mod2d(scale, B, Cn), _mod2d(shift, B, Cn), _mod2d(gate, B, Cn)
+        h, mean, rstd = ops.layernorm_fwd(x2, _f32(gamma), _f32(beta), sc, sh, rows_per_batch=N, out_dtype=cdt)
+        pre = torch.empty((B * N, Hd), dtype=cdt, device=x.device)
+        a = ops.gemm(h, cast_param(w1, cdt), bias=_f32(b1), act=ops.ACT_GELU, aux=pre, p_drop=p_drop, seed=seeds[0])
+        z = torch.empty((B * N, Cn), dtype=cdt, device=x.device) if gt is not None else None
+        out = ops.gemm(a, cast_param(w2, cdt), bias=_f32(b2), zsave=z, gate=gt, residual=x2, rows_per_batch=N,
+                       p_drop=p_drop, seed=seeds[1], out_dtype=torch.float32)
+        ctx.save_for_backward(x2, gamma, beta, sc, gt, w1, w2, h, mean, rstd, pre, a, z)
+        ctx.cfg = (B, N, Cn, cdt, p_drop, seeds, scale is not None, gate is not None)
+        return out.view(B, N, Cn)
+
+    @staticmethod
+    def backward(ctx, dout):
+        x2, gamma, beta, sc, gt, w1, w2, h, mean, rstd, pre, a, z = ctx.saved_tensors
+        B, N, Cn, cdt, p_drop, seeds, has_mod, has_gate = ctx.cfg
+        dy = _f32(dout).view(B * N, Cn)
+        dz, dgate, db2 = ops.branch_bwd(dy, z, gt, rows_per_batch=N, out_dtype=cdt, p_drop=p_drop, seed=seeds[1])
+        dw2 = ops.gemm(dz, a, a_kmajor=True, b_kmajor=True, out_dtype=torch.float32)
+        # d(pre) = (dz W2) * dropmask(fc1) * gelu'(pre): fused into the GEMM epilogue
+        dpre = ops.gemm(dz, cast_param(w2, cdt), b_kmajor=True, act=ops.ACT_GELU_GRAD, aux=pre, p_drop=p_drop, seed=seeds[0])
+        dw1 = ops.gemm(dpre, h, a_kmajor=True, b_kmajor=True, out_dtype=torch.float32)
+        db1 = ops.colsum(dpre)
+        dh = ops.gemm(dpre, cast_param(w1, cdt), b_kmajor=True)
+        dx, dg, db, dsc, dsh = ops.layernorm_bwd(dh, x2, _f32(gamma), _f32(beta), sc, mean, rstd, dres=dy, rows_per_batch=N)
+        v3 = lambda t: None if t is None else t.view(B, 1, Cn)
+        return (dx.view(B, N, Cn), dg, db, v3(dsc) if has_mod else None, v3(dsh) if has_mod else None,
+                v3(dgate) if has_gate else None, dw1, db1, dw2, db2, None, None, None)
+
+
+# --------------------------------------------------------------------------------------------
+# DRR ray sums
+# --------------------------------------------------------------------------------------------
+class DrrFn(torch.autograd.Function):
+    """Ray-sum projection of a (B,D,H,W) volume along D (axis 0) or W (axis 2)."""
+
+    @staticmethod
+    def forward(ctx, vol, axis, exp_mode, mu, out_scale, clamp_min, transpose_out):
+        v = vol.detach()
+        if v.dtype not in (torch.float32, torch.bfloat16):
+            v = v.float()
+        v = v.contiguous()
+        out = ops.drr_fwd(v, axis, exp_mode=exp_mode, mu=mu, out_scale=out_scale, clamp_min=clamp_min,
+                          transpose_out=transpose_out)
+        ctx.save_for_backward(v, out)
+        ctx.cfg = (axis, exp_mode, mu, out_scale, clamp_min, transpose_out, vol.dtype)
+        return out if out.dtype == vol.dtype else out.to(vol.dtype)
+
+    @staticmethod
+    def backward(ctx, dout):
+        v, out = ctx.saved_tensors
+        axis, exp_mode, mu, out_scale, clamp_min, transpose_out, in_dtype = ctx.cfg
+        dv = ops.drr_bwd(v, out, dout.to(v.dtype), axis, exp_mode=exp_mode, mu=mu, out_scale=out_scale,
+                         clamp_min=clamp_min, transpose_out=transpose_out)
+        return (dv if dv.dtype == in_dtype else dv.to(in_dtype)), None, None, None, None, None, None
+
+
+def drr_project(vol, axis, *, exp_mode, mu=0.3, out_scale=1.0, clamp_min=float("-inf"), transpose_out=False):
+    return DrrFn.apply(vol, axis, exp_mode, mu, out_scale, clamp_min, transpose_out)

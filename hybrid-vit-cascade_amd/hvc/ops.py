@@ -112,14 +112,23 @@ def _dense_like(t):
 ACT_NONE, ACT_GELU, ACT_GELU_GRAD = 0, 1, 2
 
 
-def gemm(a, b, *, a_kmajor=False, b_kmajor=False, alpha=1.0, bias=None, act=ACT_NONE, aux=None,
+def _unit_inner(t):
+    return t.shape[1] == 1 or t.stride(1) == 1
+
+
+def _ld(t):
+    """Leading dimension of a 2-D tensor (torch reports arbitrary strides for size-1 dims)."""
+    return t.stride(0) if t.shape[0] > 1 else t.shape[1]
+
+
+def gemm(a, b, *, a_kmajor=False, b_kmajor=False, alpha=1.0, bias=None, act=ACT_NONE, aux=None, zsave=None,
          gate=None, residual=None, rows_per_batch=0, p_drop=0.0, seed=0, out_dtype=None, out=None):
     """C[i][j] = sum_k A(i,k) B(j,k) with the fused epilogue of hvc_gemm.
 
     a: (M,K) if not a_kmajor else (K,M);  b: (N,K) if not b_kmajor else (K,N); both 2-D with unit
     inner stride.  Returns C (M,N)."""
-    _dev(a, b, bias, aux, gate, residual, out)
-    if a.dim() != 2 or b.dim() != 2 or a.stride(1) != 1 or b.stride(1) != 1:
+    _dev(a, b, bias, aux, zsave, gate, residual, out)
+    if a.dim() != 2 or b.dim() != 2 or not (_unit_inner(a) and _unit_inner(b)):
         raise ValueError("gemm operands must be 2-D with unit inner stride")
     if a.dtype != b.dtype:
         raise ValueError("gemm operands must share a dtype")
@@ -130,17 +139,20 @@ def gemm(a, b, *, a_kmajor=False, b_kmajor=False, alpha=1.0, bias=None, act=ACT_
     out_dtype = out_dtype or a.dtype
     if out is None:
         out = torch.empty((M, N), dtype=out_dtype, device=a.device)
-    elif out.shape != (M, N) or out.stride(1) != 1 or out.dtype != out_dtype:
+    elif out.shape != (M, N) or not _unit_inner(out) or out.dtype != out_dtype:
         raise ValueError("gemm: bad out tensor")
-    if aux is not None and (aux.shape != (M, N) or aux.dtype != out_dtype or aux.stride() != out.stride()):
+    if aux is not None and (aux.shape != (M, N) or aux.dtype != out_dtype or _ld(aux) != _ld(out) or not _unit_inner(aux)):
         raise ValueError("gemm: aux must match the output tensor")
     _f32c(bias, "bias"), _f32c(gate, "gate")
-    if residual is not None and (residual.dtype != torch.float32 or residual.shape != (M, N) or residual.stride(1) != 1):
+    if zsave is not None and (zsave.shape != (M, N) or zsave.dtype != a.dtype or not _unit_inner(zsave)):
+        raise ValueError("gemm: zsave must be (M,N) in the operand dtype")
+    if residual is not None and (residual.dtype != torch.float32 or residual.shape != (M, N) or not _unit_inner(residual)):
         raise ValueError("gemm: residual must be fp32 (M,N)")
     check(_lib.load().hvc_gemm(
-        a.data_ptr(), b.data_ptr(), out.data_ptr(), M, N, K, a.stride(0), b.stride(0), out.stride(0),
-        int(a_kmajor), int(b_kmajor), float(alpha), _ptr(bias), int(act), _ptr(aux), _ptr(gate),
-        _ptr(residual), residual.stride(0) if residual is not None else 0, int(rows_per_batch),
+        a.data_ptr(), b.data_ptr(), out.data_ptr(), M, N, K, _ld(a), _ld(b), _ld(out),
+        int(a_kmajor), int(b_kmajor), float(alpha), _ptr(bias), int(act), _ptr(aux), _ptr(zsave),
+        _ld(zsave) if zsave is not None else 0, _ptr(gate),
+        _ptr(residual), _ld(residual) if residual is not None else 0, int(rows_per_batch),
         float(p_drop), int(seed), _code(a.dtype), _code(out_dtype), _stream()), "hvc_gemm")
     return out
 
@@ -188,7 +200,8 @@ def layernorm_bwd(dy, x, gamma, beta, scale, mean, rstd, *, dres=None, rows_per_
 # --------------------------------------------------------------------------------------------
 # residual-branch backward, column sums, casts
 # --------------------------------------------------------------------------------------------
-def branch_bwd(dy, z=None, gate=None, *, rows_per_batch=None, out_dtype=torch.float32, want_bias=True):
+def branch_bwd(dy, z=None, gate=None, *, rows_per_batch=None, out_dtype=torch.float32, want_bias=True,
+               p_drop=0.0, seed=0):
     """dy: (rows,N) fp32.  Returns dz (rows,N) out_dtype, dgate (nbatch,N) or None, dbias (N,) or None."""
     _dev(dy, z, gate)
     _f32c(dy, "dy"), _f32c(gate, "gate")
@@ -202,7 +215,7 @@ def branch_bwd(dy, z=None, gate=None, *, rows_per_batch=None, out_dtype=torch.fl
     dgate = torch.empty((rows // rpb, N), dtype=torch.float32, device=dy.device) if (gate is not None and z is not None) else None
     dbias = torch.empty((N,), dtype=torch.float32, device=dy.device) if want_bias else None
     check(lib.hvc_branch_bwd(dy.data_ptr(), _ptr(z), _ptr(gate), dz.data_ptr(), _ptr(dgate), _ptr(dbias), ws.data_ptr(),
-                             rows, N, rpb, _code(out_dtype), _stream()), "hvc_branch_bwd")
+                             rows, N, rpb, float(p_drop), int(seed), _code(out_dtype), _stream()), "hvc_branch_bwd")
     return dz, dgate, dbias
 
 

@@ -73,7 +73,7 @@ int hvc_attention_bwd(const void* q, const void* k, const void* v, const void* o
                       float scale, float p_drop, uint64_t seed, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
- * GEMM with fused epilogue:   C = residual + gate_b * dropout(act(alpha * A B^T + bias))
+ * GEMM with fused epilogue:   z = dropout(act(alpha * A B^T + bias));  C = residual + gate_b * z
  *   C[i][j] = sum_k A(i,k) B(j,k);  an operand is k-contiguous (X[i*ld + k]) or, with *_kmajor = 1,
  *   k-major (X[k*ld + i]) -- so dx = dy W and dW = dy^T x read W / activations in place.
  * Replaces nn.Linear forward/backward at models/vit_components.py:26,28,41,54,74,75,77,95,98,115,
@@ -81,13 +81,14 @@ int hvc_attention_bwd(const void* q, const void* k, const void* v, const void* o
  * plus the gated residual adds at models/hybrid_vit_backbone.py:123,128,139.
  *   act: 0 none | 1 GELU(erf) (aux != NULL additionally receives the pre-activation, dtype/ld of C)
  *        | 2 multiply by GELU'(aux)  (backward of 1; aux = saved pre-activation)
+ *   zsave: optional [M][N] copy of z in in_dtype with leading dimension ldz (kept for the gate gradient);
  *   bias: [N] fp32 or NULL;  gate: [M / rows_per_batch][N] fp32 or NULL;
  *   residual: [M][N] fp32 with leading dimension ldr, or NULL.
  *   in_dtype / out_dtype: (BF16,BF16), (BF16,F32) or (F32,F32).
  * ---------------------------------------------------------------------------------------------- */
 int hvc_gemm(const void* A, const void* B, void* C, int M, int N, int K,
              int64_t lda, int64_t ldb, int64_t ldc, int a_kmajor, int b_kmajor, float alpha,
-             const float* bias, int act, void* aux,
+             const float* bias, int act, void* aux, void* zsave, int64_t ldz,
              const float* gate, const float* residual, int64_t ldr, int rows_per_batch,
              float p_drop, uint64_t seed, int in_dtype, int out_dtype, void* stream);
 
@@ -115,14 +116,16 @@ int hvc_layernorm_bwd(const void* dy, const float* x, const float* gamma, const 
 
 /* ------------------------------------------------------------------------------------------------
  * Backward of a (gated) residual branch  x_out = x + gate_b * z
- * (models/hybrid_vit_backbone.py:123,128,139):  dz = gate_b * dy (cast to out_dtype),
+ * (models/hybrid_vit_backbone.py:123,128,139) where z = dropout(Linear(..)) came out of hvc_gemm
+ * with the same (p_drop, seed):  dz = gate_b * dy * dropmask / (1 - p) (cast to out_dtype),
  * dgate_b[n] = sum_rows dy*z,  dbias[n] = sum_rows dz.  dy: [rows][N] fp32; z: [rows][N] out_dtype
  * or NULL (then dgate must be NULL); gate NULL = ungated (cross-attention branch).
  * ---------------------------------------------------------------------------------------------- */
 int64_t hvc_branch_bwd_workspace(int rows, int N, int rows_per_batch);
 int hvc_branch_bwd(const float* dy, const void* z, const float* gate, void* dz,
                    float* dgate, float* dbias, float* workspace,
-                   int rows, int N, int rows_per_batch, int out_dtype, void* stream);
+                   int rows, int N, int rows_per_batch, float p_drop, uint64_t seed,
+                   int out_dtype, void* stream);
 
 /* Column sum of x[M][N] (bias gradient of a Linear, models/hybrid_vit_backbone.py:76).
  * workspace: hvc_colsum_workspace(M, N) floats. */

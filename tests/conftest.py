@@ -1,0 +1,93 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "hybrid-vit-cascade_amd")
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+PROBE_LIMIT = 32768
+PROBE_N = 512
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs an MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_collection_modifyitems(config, items):
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason="no GPU in this container")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
+def probe_indices(n):
+    """Same sampler as tests/golden/make_golden.py."""
+    return np.random.default_rng(12345).integers(0, n, size=PROBE_N)
+
+
+class Golden:
+    """Read access to one golden .npz (see tests/golden/make_golden.py for the layout)."""
+
+    def __init__(self, name):
+        self.z = np.load(os.path.join(GOLDEN, name + ".npz"))
+
+    def t(self, key, dtype=torch.float32):
+        return torch.from_numpy(np.asarray(self.z[key])).to(dtype)
+
+    def group(self, prefix, dtype=torch.float32):
+        pre = prefix + "/"
+        return {k[len(pre):]: torch.from_numpy(np.asarray(self.z[k])).to(dtype if self.z[k].dtype.kind == "f" else torch.int64)
+                for k in self.z.files if k.startswith(pre) and "#" not in k}
+
+    def keys(self, prefix):
+        pre = prefix + "/"
+        return sorted({k[len(pre):].split("#")[0] for k in self.z.files if k.startswith(pre)})
+
+    @staticmethod
+    def _err(got, ref, metric):
+        # floor: exactly-zero gradients (conv bias ahead of BatchNorm) hold only rounding noise
+        if metric == "l2":     # relative Frobenius error: the right yardstick for bf16 gradients
+            return np.linalg.norm(got - ref) / max(np.linalg.norm(ref), 1e-6 * np.sqrt(ref.size))
+        return np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-6)
+
+    def check(self, prefix, name, value, rtol, atol_scale=1.0, metric="max"):
+        """Compare `value` with the stored array (full, or probes + sums for compacted entries).
+        metric 'max': max|got-ref| / max|ref| ; 'l2': ||got-ref|| / ||ref||."""
+        key = f"{prefix}/{name}" if prefix else name
+        v = value.detach().double().cpu().numpy()
+        tol = rtol * atol_scale
+        if key in self.z.files:
+            ref = self.z[key].astype(np.float64)
+            assert ref.shape == v.shape, f"{key}: shape {v.shape} vs golden {ref.shape}"
+            err = self._err(v, ref, metric)
+            assert err <= tol, f"{key}: {metric} err {err:.3e} > {tol:.1e}"
+            return err
+        ref = self.z[key + "#probe"].astype(np.float64)
+        stats = self.z[key + "#stats"]
+        assert v.size == int(stats[2]), f"{key}: size mismatch"
+        got = v.reshape(-1)[probe_indices(v.size)]
+        err = self._err(got, ref, metric)
+        assert err <= tol, f"{key} (probe): {metric} err {err:.3e} > {tol:.1e}"
+        # stats[1] = sum |x| bounds the rounding of the plain sum
+        assert abs(v.sum() - stats[0]) <= 10 * tol * stats[1] + 1e-12, f"{key}: checksum mismatch"
+        return err
+
+
+@pytest.fixture(scope="session")
+def golden():
+    cache = {}
+
+    def get(name):
+        if name not in cache:
+            cache[name] = Golden(name)
+        return cache[name]
+    return get
