@@ -116,8 +116,8 @@ int hvc_attention_bwd(const void* q, const void* k, const void* v, const void* o
 int hvc_gemm(const void* A, const void* B, void* C, int M, int N, int K,
              int64_t lda, int64_t ldb, int64_t ldc, int a_kmajor, int b_kmajor, float alpha,
              const float* bias, int act, void* aux, void* zsave, int64_t ldz, const float* gate,
-             const float* residual, int64_t ldr, int rows_per_batch, float p_drop, uint64_t seed,
-             int in_dtype, int out_dtype, void* stream) {
+             const float* residual, int64_t ldr, int residual_rows, int rows_per_batch, float p_drop, uint64_t seed,
+             float* workspace, int64_t workspace_floats, int in_dtype, int out_dtype, void* stream) {
     if (!A || !B || !C) return fail(HVC_E_BADARG, "gemm: null operand");
     if (M < 1 || N < 1 || K < 1) return fail(HVC_E_BADARG, "gemm: empty dimension");
     if (!dtype_ok(in_dtype) || !dtype_ok(out_dtype)) return fail(HVC_E_BADARG, "gemm: bad dtype");
@@ -130,7 +130,7 @@ int hvc_gemm(const void* A, const void* B, void* C, int M, int N, int K,
     memset(&g, 0, sizeof(g));
     g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K;
     g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.a_kmajor = a_kmajor != 0; g.b_kmajor = b_kmajor != 0;
-    g.alpha = alpha; g.bias = bias; g.act = act; g.aux = aux; g.zsave = zsave; g.ldz = ldz; g.gate = gate; g.residual = residual; g.ldr = ldr;
+    g.alpha = alpha; g.bias = bias; g.act = act; g.aux = aux; g.zsave = zsave; g.ldz = ldz; g.gate = gate; g.residual = residual; g.ldr = ldr; g.residual_rows = residual_rows > 0 ? residual_rows : 0;
     g.rows_per_batch = rows_per_batch > 0 ? rows_per_batch : M;
     g.seed_lo = (uint32_t)seed; g.seed_hi = (uint32_t)(seed >> 32);
     g.drop_thresh = drop_threshold(p_drop);
@@ -138,7 +138,13 @@ int hvc_gemm(const void* A, const void* B, void* C, int M, int N, int K,
     g.in_bf16 = in_dtype == HVC_BF16; g.out_bf16 = out_dtype == HVC_BF16;
     g.vec_a = aligned16(A) && (lda % 8 == 0);
     g.vec_b = aligned16(B) && (ldb % 8 == 0);
+    g.workspace = workspace; g.workspace_floats = workspace ? workspace_floats : 0;
     return hip_result(hvc::gemm_launch(g, (hipStream_t)stream), "gemm");
+}
+
+int64_t hvc_gemm_workspace(int M, int N, int K) {
+    if (M < 1 || N < 1 || K < 1) return -1;
+    return hvc::gemm_workspace_floats(M, N, K);
 }
 
 int hvc_layernorm_fwd(const float* x, const float* gamma, const float* beta, const float* scale, const float* shift,
@@ -252,6 +258,156 @@ int hvc_drr_bwd(const void* vol, const void* out, const void* dout, void* dvol, 
     if (!out || !dout || !dvol) return fail(HVC_E_BADARG, "drr_bwd: null operand");
     a.out = const_cast<void*>(out); a.dout = dout; a.dvol = dvol;
     return hip_result(hvc::drr_bwd_launch(a, (hipStream_t)stream), "drr_bwd");
+}
+
+static int fill_geom(hvc::ConvGeom& g, int B, int C, int SD, int SH, int SW, int KD, int KH, int KW, int stride,
+                     int PD, int PH, int PW, int64_t Kp) {
+    if (B < 1 || C < 1 || SD < 1 || SH < 1 || SW < 1 || KD < 1 || KH < 1 || KW < 1 || stride < 1 || PD < 0 || PH < 0 || PW < 0)
+        return fail(HVC_E_BADARG, "conv geometry: bad extent");
+    g.B = B; g.C = C; g.SD = SD; g.SH = SH; g.SW = SW; g.KD = KD; g.KH = KH; g.KW = KW; g.stride = stride;
+    g.PD = PD; g.PH = PH; g.PW = PW;
+    g.OD = (SD + 2 * PD - KD) / stride + 1; g.OH = (SH + 2 * PH - KH) / stride + 1; g.OW = (SW + 2 * PW - KW) / stride + 1;
+    if (g.OD < 1 || g.OH < 1 || g.OW < 1) return fail(HVC_E_BADARG, "conv geometry: empty output");
+    g.M = (int64_t)B * g.OD * g.OH * g.OW;
+    g.Kp = Kp;
+    if (Kp < (int64_t)KD * KH * KW * C || Kp % 8) return fail(HVC_E_BADARG, "conv geometry: Kp must be a multiple of 8 >= taps*C");
+    if (C % 8 == 0 && Kp != (int64_t)KD * KH * KW * C) return fail(HVC_E_BADARG, "conv geometry: Kp must equal taps*C when C % 8 == 0");
+    return 0;
+}
+
+int hvc_im2col(const void* src, void* col, int B, int C, int SD, int SH, int SW, int KD, int KH, int KW, int stride,
+               int PD, int PH, int PW, int64_t Kp, int dtype, void* stream) {
+    hvc::ConvGeom g;
+    int rc = fill_geom(g, B, C, SD, SH, SW, KD, KH, KW, stride, PD, PH, PW, Kp);
+    if (rc) return rc;
+    if (!src || !col || !dtype_ok(dtype)) return fail(HVC_E_BADARG, "im2col: bad operand");
+    if (C % 8 == 0 && !(aligned16(src) && aligned16(col))) return fail(HVC_E_BADARG, "im2col: operands must be 16-byte aligned");
+    return hip_result(hvc::im2col_launch(g, src, col, dtype == HVC_BF16, (hipStream_t)stream), "im2col");
+}
+
+int hvc_col2im(const void* dcol, void* dsrc, int B, int C, int SD, int SH, int SW, int KD, int KH, int KW, int stride,
+               int PD, int PH, int PW, int64_t Kp, int dtype, void* stream) {
+    hvc::ConvGeom g;
+    int rc = fill_geom(g, B, C, SD, SH, SW, KD, KH, KW, stride, PD, PH, PW, Kp);
+    if (rc) return rc;
+    if (!dcol || !dsrc || !dtype_ok(dtype)) return fail(HVC_E_BADARG, "col2im: bad operand");
+    if (C % 8 == 0 && !(aligned16(dcol) && aligned16(dsrc))) return fail(HVC_E_BADARG, "col2im: operands must be 16-byte aligned");
+    return hip_result(hvc::col2im_launch(g, dcol, dsrc, dtype == HVC_BF16, (hipStream_t)stream), "col2im");
+}
+
+int hvc_trilinear_fwd(const float* src, float* dst, int B, int d, int h, int w, int D, int H, int W, void* stream) {
+    if (!src || !dst || B < 1 || d < 1 || h < 1 || w < 1 || D < 1 || H < 1 || W < 1) return fail(HVC_E_BADARG, "trilinear: bad operand");
+    return hip_result(hvc::trilinear_launch(src, dst, B, d, h, w, D, H, W, false, (hipStream_t)stream), "trilinear_fwd");
+}
+int hvc_trilinear_bwd(const float* dout, float* dsrc, int B, int d, int h, int w, int D, int H, int W, void* stream) {
+    if (!dout || !dsrc || B < 1 || d < 1 || h < 1 || w < 1 || D < 1 || H < 1 || W < 1) return fail(HVC_E_BADARG, "trilinear: bad operand");
+    return hip_result(hvc::trilinear_launch(dout, dsrc, B, d, h, w, D, H, W, true, (hipStream_t)stream), "trilinear_bwd");
+}
+
+static bool norm_c_ok(int C) { return C >= 8 && C <= 512 && C % 8 == 0 && 256 % (C / 8) == 0; }
+
+int64_t hvc_norm_workspace(int B, int P, int C, int G) {
+    if (B < 1 || P < 1 || C < 1 || G < 1) return -1;
+    return (int64_t)B * hvc::norm_chunks(P) * 2 * C + 2 * (int64_t)B * G + 2 * (int64_t)C;
+}
+
+int hvc_groupnorm_silu_fwd(const void* x, void* y, const float* gamma, const float* beta, float* stats, float* workspace,
+                           int B, int P, int C, int G, float eps, int dtype, void* stream) {
+    if (!x || !y || !gamma || !beta || !stats || !workspace || !dtype_ok(dtype)) return fail(HVC_E_BADARG, "groupnorm: bad operand");
+    if (B < 1 || P < 1 || G < 1 || C % G) return fail(HVC_E_BADARG, "groupnorm: bad shape");
+    if (!norm_c_ok(C)) return fail(HVC_E_UNSUPPORTED, "groupnorm: C must be 8,16,32,64,128,256 or 512");
+    hvc::NormArgs a; memset(&a, 0, sizeof(a));
+    a.x = x; a.y = y; a.gamma = gamma; a.beta = beta; a.stats = stats; a.partial = workspace;
+    a.B = B; a.P = P; a.C = C; a.G = G; a.eps = eps; a.is_bf16 = dtype == HVC_BF16;
+    return hip_result(hvc::groupnorm_silu_fwd_launch(a, (hipStream_t)stream), "groupnorm_silu_fwd");
+}
+
+int hvc_groupnorm_silu_bwd(const void* x, const void* dy, void* dx, const float* gamma, const float* beta, const float* stats,
+                           float* dgamma, float* dbeta, float* workspace, int B, int P, int C, int G, int dtype, void* stream) {
+    if (!x || !dy || !dx || !gamma || !beta || !stats || !dgamma || !dbeta || !workspace || !dtype_ok(dtype))
+        return fail(HVC_E_BADARG, "groupnorm_bwd: bad operand");
+    if (B < 1 || P < 1 || G < 1 || C % G) return fail(HVC_E_BADARG, "groupnorm: bad shape");
+    if (!norm_c_ok(C)) return fail(HVC_E_UNSUPPORTED, "groupnorm: C must be 8,16,32,64,128,256 or 512");
+    hvc::NormArgs a; memset(&a, 0, sizeof(a));
+    a.x = x; a.dy = dy; a.dx = dx; a.gamma = gamma; a.beta = beta; a.stats = const_cast<float*>(stats);
+    a.dgamma = dgamma; a.dbeta = dbeta; a.partial = workspace;
+    a.gsum = workspace + (int64_t)B * hvc::norm_chunks(P) * 2 * C;
+    a.B = B; a.P = P; a.C = C; a.G = G; a.is_bf16 = dtype == HVC_BF16;
+    return hip_result(hvc::groupnorm_silu_bwd_launch(a, (hipStream_t)stream), "groupnorm_silu_bwd");
+}
+
+static int fill_pool(hvc::PoolGeom& pg, int N, int H, int W, int C, int k, int s, int p) {
+    if (N < 1 || H < 1 || W < 1 || k < 1 || s < 1 || p < 0 || k > 15) return fail(HVC_E_BADARG, "bn_relu_pool: bad geometry");
+    if (!norm_c_ok(C)) return fail(HVC_E_UNSUPPORTED, "bn_relu_pool: C must be 8,16,32,64,128,256 or 512");
+    pg.N = N; pg.H = H; pg.W = W; pg.C = C; pg.k = k; pg.s = s; pg.p = p;
+    pg.HP = (H + 2 * p - k) / s + 1; pg.WP = (W + 2 * p - k) / s + 1;
+    if (pg.HP < 1 || pg.WP < 1) return fail(HVC_E_BADARG, "bn_relu_pool: empty output");
+    return 0;
+}
+
+int hvc_bn_relu_pool_fwd(const void* x, void* y, uint8_t* amax, const float* gamma, const float* beta, float* running_mean,
+                         float* running_var, float* stats, float* workspace, int N, int H, int W, int C, int k, int s, int p,
+                         int training, float eps, float momentum, int dtype, void* stream) {
+    hvc::PoolGeom pg;
+    int rc = fill_pool(pg, N, H, W, C, k, s, p);
+    if (rc) return rc;
+    if (!x || !y || !gamma || !beta || !stats || !workspace || !dtype_ok(dtype)) return fail(HVC_E_BADARG, "bn_relu_pool: bad operand");
+    if (!training && (!running_mean || !running_var)) return fail(HVC_E_BADARG, "bn_relu_pool: eval mode needs running stats");
+    if (k > 1 && !amax) return fail(HVC_E_BADARG, "bn_relu_pool: pooling needs the arg-max buffer");
+    hvc::NormArgs a; memset(&a, 0, sizeof(a));
+    a.x = x; a.y = y; a.amax = k > 1 ? amax : nullptr; a.gamma = gamma; a.beta = beta; a.running_mean = running_mean; a.running_var = running_var;
+    a.stats = stats; a.partial = workspace; a.training = training != 0; a.eps = eps; a.momentum = momentum; a.is_bf16 = dtype == HVC_BF16;
+    return hip_result(hvc::bn_relu_pool_fwd_launch(a, pg, (hipStream_t)stream), "bn_relu_pool_fwd");
+}
+
+int hvc_bn_relu_pool_bwd(const void* x, const void* dy, const uint8_t* amax, void* dx, const float* gamma, const float* beta,
+                         const float* stats, float* dgamma, float* dbeta, float* workspace, int N, int H, int W, int C,
+                         int k, int s, int p, int training, int dtype, void* stream) {
+    hvc::PoolGeom pg;
+    int rc = fill_pool(pg, N, H, W, C, k, s, p);
+    if (rc) return rc;
+    if (!x || !dy || !dx || !gamma || !beta || !stats || !dgamma || !dbeta || !workspace || !dtype_ok(dtype))
+        return fail(HVC_E_BADARG, "bn_relu_pool_bwd: bad operand");
+    if (k > 1 && !amax) return fail(HVC_E_BADARG, "bn_relu_pool_bwd: pooling needs the arg-max buffer");
+    hvc::NormArgs a; memset(&a, 0, sizeof(a));
+    a.x = x; a.dy = dy; a.dx = dx; a.amax = k > 1 ? const_cast<uint8_t*>(amax) : nullptr; a.gamma = gamma; a.beta = beta;
+    a.stats = const_cast<float*>(stats); a.dgamma = dgamma; a.dbeta = dbeta; a.partial = workspace;
+    a.gsum = workspace + (int64_t)N * hvc::norm_chunks(H * W) * 2 * C;
+    a.training = training != 0; a.is_bf16 = dtype == HVC_BF16;
+    return hip_result(hvc::bn_relu_pool_bwd_launch(a, pg, (hipStream_t)stream), "bn_relu_pool_bwd");
+}
+
+int64_t hvc_ssim_l1_workspace(int B, int D, int H, int W) {
+    if (B < 1 || D < 1 || H < 1 || W < 1) return -1;
+    const int64_t nvox = (int64_t)B * D * H * W;
+    return 10 * nvox + 2 * (int64_t)hvc::loss_blocks(nvox);
+}
+
+static int fill_loss(hvc::LossArgs& a, const float* pred, const float* target, int B, int D, int H, int W, int window, float l1_w, float ssim_w) {
+    if (!pred || !target || B < 1 || D < 1 || H < 1 || W < 1 || window < 1 || !(window & 1)) return fail(HVC_E_BADARG, "ssim_l1: bad operand");
+    memset(&a, 0, sizeof(a));
+    a.pred = pred; a.target = target; a.B = B; a.D = D; a.H = H; a.W = W; a.window = window; a.l1_w = l1_w; a.ssim_w = ssim_w;
+    return 0;
+}
+
+int hvc_ssim_l1_fwd(const float* pred, const float* target, float* out3, float* gmaps, float* workspace,
+                    int B, int D, int H, int W, int window, float l1_w, float ssim_w, void* stream) {
+    hvc::LossArgs a;
+    int rc = fill_loss(a, pred, target, B, D, H, W, window, l1_w, ssim_w);
+    if (rc) return rc;
+    if (!out3 || !gmaps || !workspace) return fail(HVC_E_BADARG, "ssim_l1_fwd: null output");
+    a.out = out3; a.gmaps = gmaps; a.workspace = workspace;
+    return hip_result(hvc::ssim_l1_fwd_launch(a, (hipStream_t)stream), "ssim_l1_fwd");
+}
+
+int hvc_ssim_l1_bwd(const float* pred, const float* target, const float* gmaps, const float* gscale, float* dpred, float* workspace,
+                    int B, int D, int H, int W, int window, float l1_w, float ssim_w, void* stream) {
+    hvc::LossArgs a;
+    int rc = fill_loss(a, pred, target, B, D, H, W, window, l1_w, ssim_w);
+    if (rc) return rc;
+    if (!gmaps || !dpred || !workspace) return fail(HVC_E_BADARG, "ssim_l1_bwd: null operand");
+    a.gmaps = const_cast<float*>(gmaps); a.gscale = gscale; a.dpred = dpred; a.workspace = workspace;
+    return hip_result(hvc::ssim_l1_bwd_launch(a, (hipStream_t)stream), "ssim_l1_bwd");
 }
 
 }  // extern "C"

@@ -95,7 +95,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
     // of one column panel, so the B (weight) panel and A row panels stay in that XCD's L2.
     const int tiles_m = (g.M + kBM - 1) / kBM, tiles_n = (g.N + kBN - 1) / kBN;
     const int nwg = tiles_m * tiles_n;
-    int id = blockIdx.x;
+    const int split = blockIdx.x / nwg;      // split-K slice (0 when splitk == 1)
+    int id = blockIdx.x % nwg;
     {
         const int q = nwg >> 3, rem = nwg & 7, xcd = id & 7, slot = id >> 3;
         id = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + slot;
@@ -107,9 +108,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
     const TI* Bp = reinterpret_cast<const TI*>(g.B);
     TA ta;
     TB tb;
-    const int nkt = (g.K + BK - 1) / BK;
-    ta.issue(Ap, g.lda, i0, g.M, 0, g.K, g.vec_a != 0, tid);
-    tb.issue(Bp, g.ldb, j0, g.N, 0, g.K, g.vec_b != 0, tid);
+    const int nkt_all = (g.K + BK - 1) / BK;
+    const int per_split = (nkt_all + g.splitk - 1) / g.splitk;
+    const int kt_begin = split * per_split;
+    const int kt_end = min(nkt_all, kt_begin + per_split);
+    ta.issue(Ap, g.lda, i0, g.M, kt_begin * BK, g.K, g.vec_a != 0, tid);
+    tb.issue(Bp, g.ldb, j0, g.N, kt_begin * BK, g.K, g.vec_b != 0, tid);
     ta.commit(At(0), tid);
     tb.commit(Bt(0), tid);
     __syncthreads();
@@ -122,9 +126,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[mi][ni][i] = 0.f;
 
-    for (int kt = 0; kt < nkt; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nkt) {
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        const int buf = (kt - kt_begin) & 1;
+        if (kt + 1 < kt_end) {
             ta.issue(Ap, g.lda, i0, g.M, (kt + 1) * BK, g.K, g.vec_a != 0, tid);
             tb.issue(Bp, g.ldb, j0, g.N, (kt + 1) * BK, g.K, g.vec_b != 0, tid);
         }
@@ -148,13 +152,29 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
                         for (int sb = 0; sb < NS; ++sb)
                             if (sa + sb <= 1) acc[mi][ni] = mfma32(af[sa][mi], bfr[sb][ni], acc[mi][ni]);
         }
-        if (kt + 1 < nkt) {
+        if (kt + 1 < kt_end) {
             ta.commit(At(buf ^ 1), tid);
             tb.commit(Bt(buf ^ 1), tid);
         }
         __syncthreads();
     }
 
+    if (g.splitk > 1) {   // raw fp32 partial tile -> slab `split` of the workspace; reduced by splitk_reduce_kernel
+        float* ws = g.workspace + (size_t)split * g.M * g.N;
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const int j = j0 + 64 * wn + 32 * ni + r;
+            if (j >= g.N) continue;
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int x = 0; x < 16; ++x) {
+                    const int i = i0 + 64 * wm + 32 * mi + acc_row(x, h);
+                    if (i < g.M) ws[(size_t)i * g.N + j] = acc[mi][ni][x];
+                }
+        }
+        return;
+    }
     // epilogue: rows in registers, columns on lanes -> each store instruction writes 32
     // consecutive columns of one row.
     TO* Cp = reinterpret_cast<TO*>(g.C);
@@ -186,15 +206,28 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
                 }
                 if (zp) zp[(int64_t)i * g.ldz + j] = from_f<TI>(v);
                 if (g.gate) v *= g.gate[(int64_t)(i / g.rows_per_batch) * g.N + j];
-                if (g.residual) v += g.residual[(int64_t)i * g.ldr + j];
+                if (g.residual) v += g.residual[(int64_t)(g.residual_rows > 0 ? i % g.residual_rows : i) * g.ldr + j];
                 Cp[(int64_t)i * g.ldc + j] = from_f<TO>(v);
             }
         }
     }
 }
 
+template <typename TO>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs g) {
+    const size_t total = (size_t)g.M * g.N;
+    TO* Cp = reinterpret_cast<TO*>(g.C);
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        float s = 0.f;
+        for (int k = 0; k < g.splitk; ++k) s += g.workspace[(size_t)k * total + e];   // fixed order: deterministic
+        const size_t i = e / g.N, j = e % g.N;
+        Cp[i * g.ldc + j] = from_f<TO>(s * g.alpha);
+    }
+}
+
 template <typename TI, typename TO, bool AKM, bool BKM>
-hipError_t launch(const GemmArgs& g, hipStream_t st) {
+hipError_t launch(const GemmArgs& g_in, hipStream_t st) {
+    GemmArgs g = g_in;
     constexpr int NS = NSplit<TI>::value;
     constexpr int BK = sizeof(TI) == 2 ? 64 : 32;
     const size_t lds = (size_t)2 * 2 * NS * 128 * BK * sizeof(bf16);
@@ -204,7 +237,25 @@ hipError_t launch(const GemmArgs& g, hipStream_t st) {
         if (e != hipSuccess) return e;
     }
     const int tiles = ((g.M + kBM - 1) / kBM) * ((g.N + kBN - 1) / kBN);
-    hipLaunchKernelGGL(k, dim3(tiles), dim3(256), lds, st, g);
+    const int nkt = (g.K + BK - 1) / BK;
+    // Split-K: a weight-gradient GEMM has a tiny output (N_out x K_in) and a contraction over all
+    // tokens, i.e. a dozen tiles for 256 CUs.  Slice K over workgroups into fp32 slabs and reduce
+    // them in a fixed order (deterministic; no float atomics).
+    g.splitk = 1;
+    const bool plain = !g.bias && g.act == kActNone && !g.aux && !g.zsave && !g.gate && !g.residual && !g.drop_thresh;
+    if (plain && g.workspace && tiles <= 128 && nkt >= 8) {
+        int want = (768 + tiles - 1) / tiles;
+        if (want > nkt / 2) want = nkt / 2;
+        const int64_t fit = g.workspace_floats / ((int64_t)g.M * g.N);
+        if (want > fit) want = (int)fit;
+        if (want >= 2) g.splitk = want;
+    }
+    hipLaunchKernelGGL(k, dim3(tiles * g.splitk), dim3(256), lds, st, g);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || g.splitk == 1) return e;
+    int blocks = (int)(((size_t)g.M * g.N + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(splitk_reduce_kernel<TO>, dim3(blocks), dim3(256), 0, st, g);
     return hipGetLastError();
 }
 
@@ -215,6 +266,15 @@ hipError_t launch_layout(const GemmArgs& g, hipStream_t st) {
 }
 
 }  // namespace
+
+int64_t gemm_workspace_floats(int M, int N, int K) {
+    const int tiles = ((M + kBM - 1) / kBM) * ((N + kBN - 1) / kBN);
+    if (tiles > 128 || K < 8 * 32) return 0;
+    int want = (768 + tiles - 1) / tiles;
+    const int nkt = (K + 31) / 32;
+    if (want > nkt / 2) want = nkt / 2;
+    return want >= 2 ? (int64_t)want * M * N : 0;
+}
 
 hipError_t gemm_launch(const GemmArgs& g, hipStream_t st) {
     if (g.in_bf16) return g.out_bf16 ? launch_layout<bf16, bf16>(g, st) : launch_layout<bf16, float>(g, st);

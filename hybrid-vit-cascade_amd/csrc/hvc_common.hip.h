@@ -115,15 +115,24 @@ __device__ __forceinline__ void acc_split(const float (&x)[8], bf16x8 (&out)[NS]
 }
 
 // ---------------------------------------------------------------------------------
-// LDS tile image: R rows of CW bf16 (CW = 32 or 64 => 64 / 128-byte rows), 16-byte
-// chunks XOR-swizzled so that the 16 rows a ds_read_b128 lane group touches land on
-// 16 different 16-byte slots of the 256-byte bank row.
+// LDS tile image: R rows of CW bf16 (CW = 32 / 64 / 128 => 64 / 128 / 256-byte rows) with the
+// 16-byte chunks of each row XOR-swizzled.
 // ---------------------------------------------------------------------------------
 template <int CW>
 __device__ __forceinline__ int tile_off(int row, int chunk) {   // offset in bf16 elements
-    constexpr int CPR = CW / 8;          // chunks per row (4 or 8)
-    constexpr int RPB = 16 / CPR;        // rows per 256-byte bank row (4 or 2)
-    int sw = chunk ^ ((row / RPB) & (CPR - 1));
+    // One swizzle per row width serves both read kinds (MI355X LDS: banks = (addr/4) % 64):
+    //  * ds_read_b128 row fragments: the 16 rows of a lane group must land on 16 distinct 16-byte slots
+    //  * ds_read_b64_tr_b16: the 4 consecutive rows x 4 consecutive chunks a 32-lane half touches
+    //    must land on 16 distinct slots as well.
+    int sw;
+    if constexpr (CW == 128) {          // 256-byte rows: every row starts on bank 0
+        sw = chunk ^ (((row & 3) << 2) | ((row >> 2) & 3));
+    } else if constexpr (CW == 64) {    // 128-byte rows: 2 rows per bank row
+        sw = chunk ^ ((((row >> 1) & 1) << 2) | ((row >> 2) & 3));
+    } else {                            // 64-byte rows: 4 rows per bank row
+        static_assert(CW == 32, "tile width must be 32, 64 or 128 bf16");
+        sw = chunk ^ ((row >> 2) & 3);
+    }
     return row * CW + sw * 8;
 }
 

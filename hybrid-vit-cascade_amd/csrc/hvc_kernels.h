@@ -49,12 +49,17 @@ struct GemmArgs {
     const float* gate;       // [M / rows_per_batch][N] or null
     const float* residual;   // [M][N] fp32, ldr, or null
     int64_t ldr;
+    int residual_rows;       // > 0: residual has this many rows and is indexed by i % residual_rows (pos_embed broadcast)
     int rows_per_batch;
     uint32_t seed_lo, seed_hi, drop_thresh;
     float keep_scale;
     int in_bf16, out_bf16;
     int vec_a, vec_b;
+    float* workspace;        // optional split-K scratch (fp32), workspace_floats long
+    int64_t workspace_floats;
+    int splitk;              // filled in by the launcher
 };
+int64_t gemm_workspace_floats(int M, int N, int K);
 hipError_t gemm_launch(const GemmArgs& g, hipStream_t st);
 
 struct LnArgs {
@@ -117,5 +122,51 @@ struct DrrArgs {
 };
 hipError_t drr_fwd_launch(const DrrArgs& a, hipStream_t st);
 hipError_t drr_bwd_launch(const DrrArgs& a, hipStream_t st);
+
+struct ConvGeom {
+    int B, C;               // batch, source channels
+    int SD, SH, SW;         // source extent (channels-last [B][SD][SH][SW][C])
+    int OD, OH, OW;         // patch-grid extent
+    int KD, KH, KW, stride, PD, PH, PW;
+    int64_t M;              // B * OD * OH * OW
+    int64_t Kp;             // row pitch of the patch matrix (>= KD*KH*KW*C, multiple of 8)
+};
+hipError_t im2col_launch(const ConvGeom& g, const void* src, void* col, int is_bf16, hipStream_t st);
+hipError_t col2im_launch(const ConvGeom& g, const void* dcol, void* dsrc, int is_bf16, hipStream_t st);
+hipError_t trilinear_launch(const float* src, float* dst, int B, int d, int h, int w, int D, int H, int W, bool bwd, hipStream_t st);
+
+struct PoolGeom { int N, H, W, C, HP, WP, k, s, p; };
+struct NormArgs {
+    const void* x; void* y; const void* dy; void* dx;
+    const float* gamma; const float* beta;
+    float* stats;            // GN: [B][G][2] (mean, rstd); BN: [C][2]
+    float* partial;          // [B][chunks][2][C]
+    float* gsum;             // GN bwd: [B][G][2]; BN bwd: [C][2] means of ds, ds*xhat
+    float* dgamma; float* dbeta;
+    float* running_mean; float* running_var;
+    uint8_t* amax;
+    int B, P, C, G;
+    float eps, momentum;
+    int training, is_bf16;
+};
+int norm_chunks(int P);
+hipError_t groupnorm_silu_fwd_launch(const NormArgs& a, hipStream_t st);
+hipError_t groupnorm_silu_bwd_launch(const NormArgs& a, hipStream_t st);
+hipError_t bn_relu_pool_fwd_launch(const NormArgs& a, const PoolGeom& pg, hipStream_t st);
+hipError_t bn_relu_pool_bwd_launch(const NormArgs& a, const PoolGeom& pg, hipStream_t st);
+
+struct LossArgs {
+    const float* pred; const float* target;
+    float* out;              // [3] total, l1, ssim-loss
+    float* gmaps;            // [3][nvox] derivative maps (fwd out / bwd in)
+    float* workspace;
+    const float* gscale;     // device [3]: upstream gradients of (total, l1, ssim_loss), or null (= 1, 0, 0)
+    float* dpred;
+    int B, D, H, W, window;
+    float l1_w, ssim_w;
+};
+int loss_blocks(int64_t nvox);
+hipError_t ssim_l1_fwd_launch(const LossArgs& a, hipStream_t st);
+hipError_t ssim_l1_bwd_launch(const LossArgs& a, hipStream_t st);
 
 }  // namespace hvc

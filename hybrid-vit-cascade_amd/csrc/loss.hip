@@ -1,0 +1,160 @@
+// Fused L1 + SSIM training loss on (B, 1, D, H, W) volumes, forward and backward, gfx950 (HBM-bound).
+//
+// Reference: direct_regression/model_direct.py:88-131 (compute_ssim_loss: five avg_pool3d(11, stride 1,
+// pad 5) maps + an elementwise formula; DirectRegressionLoss = l1_w * L1 + ssim_w * (1 - mean SSIM)).
+// avg_pool3d's default count_include_pad=True divides every window by 11^3, so each box mean is a
+// zero-padded separable running sum: three axis passes instead of 1331-tap windows.
+//   forward : pass W computes p, t, p^2, t^2, pt on the fly and box-sums them along W (5 maps),
+//             pass H, then pass D fused with the SSIM formula, the three partial-derivative maps
+//             (dS/dmu_p, dS/dE[p^2], dS/dE[pt]) and the block partial sums of S and |p - t|.
+//   backward: the three derivative maps are box-filtered (self-adjoint filter) and combined:
+//             dL/dp = l1_w sign(p-t)/n - ssim_w/n * (box(GA) + 2 p box(GPP) + t box(GPT)).
+#include "hvc_common.hip.h"
+#include "hvc_kernels.h"
+
+namespace hvc {
+namespace {
+
+// out[q][...] = sum_{|dw| <= R} f_q(p, t)[.., w + dw]   for the five SSIM moments
+__global__ __launch_bounds__(256) void ssim_pass_w_kernel(const float* __restrict__ p, const float* __restrict__ t, float* __restrict__ out,
+                                                           int64_t rows, int W, int R) {
+    const int64_t total = rows * W;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int w = (int)(idx % W);
+        const int64_t base = idx - w;
+        float s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0;
+        const int lo = max(0, w - R), hi = min(W - 1, w + R);
+        for (int x = lo; x <= hi; ++x) {
+            const float a = p[base + x], b = t[base + x];
+            s0 += a; s1 += b; s2 += a * a; s3 += b * b; s4 += a * b;
+        }
+        out[idx] = s0; out[total + idx] = s1; out[2 * total + idx] = s2; out[3 * total + idx] = s3; out[4 * total + idx] = s4;
+    }
+}
+
+// generic zero-padded box sum of nmaps volumes [n][L0][axis][inner] along `axis` (stride = inner)
+__global__ __launch_bounds__(256) void box_axis_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t total, int len, int64_t inner, int R) {
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int a = (int)((idx / inner) % len);
+        const int lo = max(0, a - R), hi = min(len - 1, a + R);
+        float s = 0.f;
+        for (int x = lo; x <= hi; ++x) s += in[idx + (int64_t)(x - a) * inner];
+        out[idx] = s;
+    }
+}
+
+// last axis pass (along D) fused with the SSIM point function.
+// in: 5 maps box-summed along W and H; writes GA, GPP, GPT (3 maps) and block partials (sum S, sum |p - t|).
+__global__ __launch_bounds__(256) void ssim_point_kernel(const float* __restrict__ in, const float* __restrict__ p, const float* __restrict__ t,
+                                                          float* __restrict__ gmaps, float* __restrict__ partial,
+                                                          int64_t nvox, int D, int64_t HW, int R, float inv_win) {
+    __shared__ float red[2][4];
+    const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+    float accS = 0.f, accL = 0.f;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < nvox; idx += (int64_t)gridDim.x * 256) {
+        const int d = (int)((idx / HW) % D);
+        const int lo = max(0, d - R), hi = min(D - 1, d + R);
+        float m[5] = {0, 0, 0, 0, 0};
+        for (int x = lo; x <= hi; ++x) {
+            const int64_t o = idx + (int64_t)(x - d) * HW;
+#pragma unroll
+            for (int q = 0; q < 5; ++q) m[q] += in[q * nvox + o];
+        }
+        const float a = m[0] * inv_win, b = m[1] * inv_win, epp = m[2] * inv_win, ett = m[3] * inv_win, ept = m[4] * inv_win;
+        const float N1 = 2.f * a * b + C1, N2 = 2.f * (ept - a * b) + C2;
+        const float D1 = a * a + b * b + C1, D2 = (epp - a * a) + (ett - b * b) + C2;
+        const float S = (N1 * N2) / (D1 * D2);
+        gmaps[idx] = S * (2.f * b / N1 - 2.f * b / N2 - 2.f * a / D1 + 2.f * a / D2);   // dS/dmu_p
+        gmaps[nvox + idx] = -S / D2;                                                      // dS/dE[p^2]
+        gmaps[2 * nvox + idx] = 2.f * S / N2;                                             // dS/dE[pt]
+        accS += S;
+        accL += fabsf(p[idx] - t[idx]);
+    }
+    accS = wave_sum(accS);
+    accL = wave_sum(accL);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { red[0][wave] = accS; red[1][wave] = accL; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        partial[2 * blockIdx.x] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        partial[2 * blockIdx.x + 1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    }
+}
+
+// out[0] = total, out[1] = l1, out[2] = ssim loss
+__global__ void loss_finish_kernel(const float* __restrict__ partial, int nblk, float* out, double inv_n, float l1_w, float ssim_w) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double s = 0.0, l = 0.0;
+    for (int i = 0; i < nblk; ++i) { s += partial[2 * i]; l += partial[2 * i + 1]; }
+    const float l1 = (float)(l * inv_n), ss = (float)(1.0 - s * inv_n);
+    out[0] = l1_w * l1 + ssim_w * ss;
+    out[1] = l1;
+    out[2] = ss;
+}
+
+// last backward axis pass (along D) fused with the combination into dpred
+__global__ __launch_bounds__(256) void ssim_grad_kernel(const float* __restrict__ g /*3 maps filtered along W,H*/, const float* __restrict__ p,
+                                                         const float* __restrict__ t, const float* __restrict__ gscale, float* __restrict__ dp,
+                                                         int64_t nvox, int D, int64_t HW, int R, float inv_win, float l1_w, float ssim_w) {
+    // upstream gradients of (total, l1, ssim_loss): fold them into effective weights
+    const float el1 = gscale ? gscale[0] * l1_w + gscale[1] : l1_w;
+    const float ess = gscale ? gscale[0] * ssim_w + gscale[2] : ssim_w;
+    const float inv_n = 1.f / (float)nvox;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < nvox; idx += (int64_t)gridDim.x * 256) {
+        const int d = (int)((idx / HW) % D);
+        const int lo = max(0, d - R), hi = min(D - 1, d + R);
+        float m0 = 0, m1 = 0, m2 = 0;
+        for (int x = lo; x <= hi; ++x) {
+            const int64_t o = idx + (int64_t)(x - d) * HW;
+            m0 += g[o]; m1 += g[nvox + o]; m2 += g[2 * nvox + o];
+        }
+        const float pv = p[idx], tv = t[idx];
+        const float dS = (m0 + 2.f * pv * m1 + tv * m2) * inv_win;
+        const float diff = pv - tv;
+        const float sgn = diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f);
+        dp[idx] = inv_n * (el1 * sgn - ess * dS);
+    }
+}
+
+int grid_for(int64_t work) {
+    int64_t blocks = (work + 255) / 256;
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    if (blocks < 1) blocks = 1;
+    return (int)blocks;
+}
+
+}  // namespace
+
+int loss_blocks(int64_t nvox) { return grid_for(nvox); }
+
+// workspace layout (floats): [5 nvox] A | [5 nvox] B | [2 * blocks] partial ;  gmaps: [3 nvox] (kept for backward)
+hipError_t ssim_l1_fwd_launch(const LossArgs& a, hipStream_t st) {
+    const int64_t nvox = (int64_t)a.B * a.D * a.H * a.W, HW = (int64_t)a.H * a.W;
+    const int R = a.window / 2;
+    const float inv_win = 1.f / ((float)a.window * a.window * a.window);
+    float* A = a.workspace;
+    float* Bw = a.workspace + 5 * nvox;
+    float* partial = a.workspace + 10 * nvox;
+    const int nblk = loss_blocks(nvox);
+    hipLaunchKernelGGL(ssim_pass_w_kernel, dim3(grid_for(nvox)), dim3(256), 0, st, a.pred, a.target, A, nvox / a.W, a.W, R);
+    hipLaunchKernelGGL(box_axis_kernel, dim3(grid_for(5 * nvox)), dim3(256), 0, st, A, Bw, 5 * nvox, a.H, (int64_t)a.W, R);
+    hipLaunchKernelGGL(ssim_point_kernel, dim3(nblk), dim3(256), 0, st, Bw, a.pred, a.target, a.gmaps, partial, nvox, a.D, HW, R, inv_win);
+    hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(64), 0, st, partial, nblk, a.out, 1.0 / (double)nvox, a.l1_w, a.ssim_w);
+    return hipGetLastError();
+}
+
+// workspace (floats): [3 nvox] A | [3 nvox] B
+hipError_t ssim_l1_bwd_launch(const LossArgs& a, hipStream_t st) {
+    const int64_t nvox = (int64_t)a.B * a.D * a.H * a.W, HW = (int64_t)a.H * a.W;
+    const int R = a.window / 2;
+    const float inv_win = 1.f / ((float)a.window * a.window * a.window);
+    float* A = a.workspace;
+    float* Bw = a.workspace + 3 * nvox;
+    hipLaunchKernelGGL(box_axis_kernel, dim3(grid_for(3 * nvox)), dim3(256), 0, st, a.gmaps, A, 3 * nvox, a.W, (int64_t)1, R);
+    hipLaunchKernelGGL(box_axis_kernel, dim3(grid_for(3 * nvox)), dim3(256), 0, st, A, Bw, 3 * nvox, a.H, (int64_t)a.W, R);
+    hipLaunchKernelGGL(ssim_grad_kernel, dim3(grid_for(nvox)), dim3(256), 0, st, Bw, a.pred, a.target, a.gscale, a.dpred, nvox, a.D, HW, R, inv_win,
+                       a.l1_w, a.ssim_w);
+    return hipGetLastError();
+}
+
+}  // namespace hvc

@@ -1,0 +1,244 @@
+// Spatial data movement for the conv stems and the output head (HBM-bound kernels, gfx950).
+//
+// Convolutions of the reference
+//   models/hybrid_vit_backbone.py:195-210   Conv3d(k3, s1|s2, p1) voxel-embed stem
+//   models/diagnostic_losses.py:82-96       Conv2d(k7 s2 p3), Conv2d(k3 s1 p1) X-ray stem
+// run as   im2col (this file)  ->  MFMA GEMM with fused bias / pos_embed epilogue (gemm.hip)
+// on CHANNELS-LAST activations [B][D][H][W][C] (2-D: D = 1), so the K index (tap, c) of a patch
+// row is a run of 16-byte aligned channel vectors, the GEMM output [positions][Cout] is already
+// the next layer's channels-last input, and the last stem layer's output IS the (B, N, C) token
+// matrix with n = (d*H' + h)*W' + w (reference :255) -- no transpose pass.
+// Backward: dcol = dOut W (GEMM, W read in place) -> col2im gather (deterministic, no atomics);
+// dW = dOut^T col (split-K GEMM).
+//
+// Also here: trilinear upsample with align_corners=True (reference models/hybrid_vit_backbone.py:272),
+// forward as a gather and backward as an output-stationary gather (each coarse voxel sums the
+// fine voxels in its support: deterministic, no atomics).
+#include "hvc_common.hip.h"
+#include "hvc_kernels.h"
+
+namespace hvc {
+namespace {
+
+struct Pos { int b, d, h, w; };
+
+__device__ __forceinline__ Pos decode(int64_t m, int D, int H, int W) {
+    Pos p;
+    p.w = (int)(m % W); m /= W;
+    p.h = (int)(m % H); m /= H;
+    p.d = (int)(m % D); p.b = (int)(m / D);
+    return p;
+}
+
+// ---- im2col ---------------------------------------------------------------------------------------
+// col[m][tap*C + c] = src[b][od*s + kd - p][oh*s + kh - p][ow*s + kw - p][c]  (0 outside), m = output position
+template <typename T, bool VEC>
+__global__ __launch_bounds__(256) void im2col_kernel(const ConvGeom g, const T* __restrict__ src, T* __restrict__ col) {
+    const int taps = g.KD * g.KH * g.KW;
+    if constexpr (VEC) {
+        const int c8n = g.C / 8;
+        const int64_t total = g.M * taps * c8n;
+        for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+            const int c8 = (int)(idx % c8n);
+            const int tap = (int)((idx / c8n) % taps);
+            const int64_t m = idx / ((int64_t)c8n * taps);
+            const Pos o = decode(m, g.OD, g.OH, g.OW);
+            const int kw = tap % g.KW, kh = (tap / g.KW) % g.KH, kd = tap / (g.KW * g.KH);
+            const int sd = o.d * g.stride + kd - g.PD, sh = o.h * g.stride + kh - g.PH, sw = o.w * g.stride + kw - g.PW;
+            const bool ok = sd >= 0 && sd < g.SD && sh >= 0 && sh < g.SH && sw >= 0 && sw < g.SW;
+            Chunk8<T> v = zero_chunk<T>();
+            if (ok) v = load_chunk<T>(src + ((((int64_t)o.b * g.SD + sd) * g.SH + sh) * g.SW + sw) * g.C + c8 * 8, 8, true);
+            T* dst = col + m * g.Kp + (int64_t)tap * g.C + c8 * 8;
+            if constexpr (sizeof(T) == 2) *reinterpret_cast<bf16x8*>(dst) = v.v;
+            else { *reinterpret_cast<f32x4*>(dst) = v.a; *reinterpret_cast<f32x4*>(dst + 4) = v.b; }
+        }
+    } else {
+        const int64_t total = g.M * g.Kp;
+        for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+            const int k = (int)(idx % g.Kp);
+            const int64_t m = idx / g.Kp;
+            float v = 0.f;
+            if (k < taps * g.C) {
+                const int c = k % g.C, tap = k / g.C;
+                const Pos o = decode(m, g.OD, g.OH, g.OW);
+                const int kw = tap % g.KW, kh = (tap / g.KW) % g.KH, kd = tap / (g.KW * g.KH);
+                const int sd = o.d * g.stride + kd - g.PD, sh = o.h * g.stride + kh - g.PH, sw = o.w * g.stride + kw - g.PW;
+                if (sd >= 0 && sd < g.SD && sh >= 0 && sh < g.SH && sw >= 0 && sw < g.SW)
+                    v = to_f<T>(src[((((int64_t)o.b * g.SD + sd) * g.SH + sh) * g.SW + sw) * g.C + c]);
+            }
+            col[idx] = from_f<T>(v);
+        }
+    }
+}
+
+// ---- col2im (gather form): dsrc[pos][c] = sum over (m, tap) with src(m, tap) == pos of dcol[m][tap*C + c] ----
+template <typename T, bool VEC>
+__global__ __launch_bounds__(256) void col2im_kernel(const ConvGeom g, const T* __restrict__ dcol, T* __restrict__ dsrc) {
+    const int taps = g.KD * g.KH * g.KW;
+    constexpr int E = VEC ? 8 : 1;
+    const int cn = g.C / E;
+    const int64_t total = (int64_t)g.B * g.SD * g.SH * g.SW * cn;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int ce = (int)(idx % cn);
+        const Pos s = decode(idx / cn, g.SD, g.SH, g.SW);
+        float acc[E];
+#pragma unroll
+        for (int j = 0; j < E; ++j) acc[j] = 0.f;
+        for (int kd = 0; kd < g.KD; ++kd) {
+            const int nd = s.d + g.PD - kd;
+            if (nd < 0 || nd % g.stride) continue;
+            const int od = nd / g.stride;
+            if (od >= g.OD) continue;
+            for (int kh = 0; kh < g.KH; ++kh) {
+                const int nh = s.h + g.PH - kh;
+                if (nh < 0 || nh % g.stride) continue;
+                const int oh = nh / g.stride;
+                if (oh >= g.OH) continue;
+                for (int kw = 0; kw < g.KW; ++kw) {
+                    const int nw = s.w + g.PW - kw;
+                    if (nw < 0 || nw % g.stride) continue;
+                    const int ow = nw / g.stride;
+                    if (ow >= g.OW) continue;
+                    const int64_t m = (((int64_t)s.b * g.OD + od) * g.OH + oh) * g.OW + ow;
+                    const int tap = (kd * g.KH + kh) * g.KW + kw;
+                    const T* p = dcol + m * g.Kp + (int64_t)tap * g.C + ce * E;
+                    if constexpr (VEC) {
+                        Chunk8<T> v = load_chunk<T>(p, 8, true);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) acc[j] += chunk_get<T>(v, j);
+                    } else {
+                        acc[0] += to_f<T>(p[0]);
+                    }
+                }
+            }
+        }
+        T* dst = dsrc + (idx / cn) * g.C + ce * E;
+        if constexpr (VEC) {
+            if constexpr (sizeof(T) == 2) {
+                bf16x8 o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = f2bf(acc[j]);
+                *reinterpret_cast<bf16x8*>(dst) = o;
+            } else {
+                *reinterpret_cast<f32x4*>(dst) = f32x4{acc[0], acc[1], acc[2], acc[3]};
+                *reinterpret_cast<f32x4*>(dst + 4) = f32x4{acc[4], acc[5], acc[6], acc[7]};
+            }
+        } else {
+            dst[0] = from_f<T>(acc[0]);
+        }
+    }
+}
+
+// ---- trilinear, align_corners = True, single channel volumes [B][d][h][w] -> [B][D][H][W] ----------
+__device__ __forceinline__ float ac_scale(int in, int out) { return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f; }
+
+__global__ __launch_bounds__(256) void trilinear_fwd_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                             int B, int d, int h, int w, int D, int H, int W) {
+    const float rd = ac_scale(d, D), rh = ac_scale(h, H), rw = ac_scale(w, W);
+    const int64_t total = (int64_t)B * D * H * W;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const Pos o = decode(idx, D, H, W);
+        const float fd = rd * o.d, fh = rh * o.h, fw = rw * o.w;
+        const int d0 = (int)fd, h0 = (int)fh, w0 = (int)fw;
+        const int d1 = min(d0 + 1, d - 1), h1 = min(h0 + 1, h - 1), w1 = min(w0 + 1, w - 1);
+        const float ld = fd - d0, lh = fh - h0, lw = fw - w0;
+        const float* s = src + (int64_t)o.b * d * h * w;
+        auto at = [&](int a, int b2, int c) { return s[((int64_t)a * h + b2) * w + c]; };
+        const float v = (1 - ld) * ((1 - lh) * ((1 - lw) * at(d0, h0, w0) + lw * at(d0, h0, w1)) + lh * ((1 - lw) * at(d0, h1, w0) + lw * at(d0, h1, w1))) +
+                        ld * ((1 - lh) * ((1 - lw) * at(d1, h0, w0) + lw * at(d1, h0, w1)) + lh * ((1 - lw) * at(d1, h1, w0) + lw * at(d1, h1, w1)));
+        dst[idx] = v;
+    }
+}
+
+// weight of fine index o onto coarse index i along one axis (mirrors the forward's i0 / i1 / lambda)
+__device__ __forceinline__ float axis_w(int o, int i, float r, int in) {
+    const float f = r * o;
+    const int i0 = (int)f;
+    const int i1 = min(i0 + 1, in - 1);
+    const float l = f - i0;
+    float wgt = 0.f;
+    if (i == i0) wgt += 1.f - l;
+    if (i == i1) wgt += l;
+    return wgt;
+}
+__device__ __forceinline__ void axis_range(int i, float r, int in, int out, int& lo, int& hi) {
+    if (r <= 0.f) { lo = 0; hi = out - 1; return; }
+    lo = max(0, (int)floorf((i - 1) / r) - 1);
+    hi = min(out - 1, (int)ceilf((i + 1) / r) + 1);
+}
+
+__global__ __launch_bounds__(256) void trilinear_bwd_kernel(const float* __restrict__ dout, float* __restrict__ dsrc,
+                                                             int B, int d, int h, int w, int D, int H, int W) {
+    const float rd = ac_scale(d, D), rh = ac_scale(h, H), rw = ac_scale(w, W);
+    const int64_t total = (int64_t)B * d * h * w;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const Pos s = decode(idx, d, h, w);
+        int dlo, dhi, hlo, hhi, wlo, whi;
+        axis_range(s.d, rd, d, D, dlo, dhi);
+        axis_range(s.h, rh, h, H, hlo, hhi);
+        axis_range(s.w, rw, w, W, wlo, whi);
+        const float* g = dout + (int64_t)s.b * D * H * W;
+        float acc = 0.f;
+        for (int od = dlo; od <= dhi; ++od) {
+            const float wd = axis_w(od, s.d, rd, d);
+            if (wd == 0.f) continue;
+            for (int oh = hlo; oh <= hhi; ++oh) {
+                const float wh = axis_w(oh, s.h, rh, h);
+                if (wh == 0.f) continue;
+                float row = 0.f;
+                for (int ow = wlo; ow <= whi; ++ow) {
+                    const float ww = axis_w(ow, s.w, rw, w);
+                    if (ww != 0.f) row += ww * g[((int64_t)od * H + oh) * W + ow];
+                }
+                acc += wd * wh * row;
+            }
+        }
+        dsrc[idx] = acc;
+    }
+}
+
+int grid_for(int64_t work) {
+    int64_t blocks = (work + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (blocks < 1) blocks = 1;
+    return (int)blocks;
+}
+
+}  // namespace
+
+hipError_t im2col_launch(const ConvGeom& g, const void* src, void* col, int is_bf16, hipStream_t st) {
+    const bool vec = (g.C % 8) == 0;
+    const int taps = g.KD * g.KH * g.KW;
+    const int64_t work = vec ? g.M * taps * (g.C / 8) : g.M * g.Kp;
+    dim3 grid(grid_for(work)), blk(256);
+    if (is_bf16) {
+        if (vec) hipLaunchKernelGGL((im2col_kernel<bf16, true>), grid, blk, 0, st, g, (const bf16*)src, (bf16*)col);
+        else hipLaunchKernelGGL((im2col_kernel<bf16, false>), grid, blk, 0, st, g, (const bf16*)src, (bf16*)col);
+    } else {
+        if (vec) hipLaunchKernelGGL((im2col_kernel<float, true>), grid, blk, 0, st, g, (const float*)src, (float*)col);
+        else hipLaunchKernelGGL((im2col_kernel<float, false>), grid, blk, 0, st, g, (const float*)src, (float*)col);
+    }
+    return hipGetLastError();
+}
+
+hipError_t col2im_launch(const ConvGeom& g, const void* dcol, void* dsrc, int is_bf16, hipStream_t st) {
+    const bool vec = (g.C % 8) == 0;
+    const int64_t work = (int64_t)g.B * g.SD * g.SH * g.SW * (vec ? g.C / 8 : g.C);
+    dim3 grid(grid_for(work)), blk(256);
+    if (is_bf16) {
+        if (vec) hipLaunchKernelGGL((col2im_kernel<bf16, true>), grid, blk, 0, st, g, (const bf16*)dcol, (bf16*)dsrc);
+        else hipLaunchKernelGGL((col2im_kernel<bf16, false>), grid, blk, 0, st, g, (const bf16*)dcol, (bf16*)dsrc);
+    } else {
+        if (vec) hipLaunchKernelGGL((col2im_kernel<float, true>), grid, blk, 0, st, g, (const float*)dcol, (float*)dsrc);
+        else hipLaunchKernelGGL((col2im_kernel<float, false>), grid, blk, 0, st, g, (const float*)dcol, (float*)dsrc);
+    }
+    return hipGetLastError();
+}
+
+hipError_t trilinear_launch(const float* src, float* dst, int B, int d, int h, int w, int D, int H, int W, bool bwd, hipStream_t st) {
+    if (!bwd) hipLaunchKernelGGL(trilinear_fwd_kernel, dim3(grid_for((int64_t)B * D * H * W)), dim3(256), 0, st, src, dst, B, d, h, w, D, H, W);
+    else hipLaunchKernelGGL(trilinear_bwd_kernel, dim3(grid_for((int64_t)B * d * h * w)), dim3(256), 0, st, src, dst, B, d, h, w, D, H, W);
+    return hipGetLastError();
+}
+
+}  // namespace hvc

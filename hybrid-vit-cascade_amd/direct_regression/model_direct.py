@@ -11,6 +11,7 @@ _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if _PKG not in sys.path:          # same cwd-relative trick as the reference (model_direct.py:9)
     sys.path.insert(0, _PKG)
 
+from hvc import functional as HF  # noqa: E402
 from models.diagnostic_losses import XrayConditioningModule  # noqa: E402
 from models.hybrid_vit_backbone import HybridViT3D  # noqa: E402
 
@@ -40,19 +41,10 @@ class DirectCTRegression(nn.Module):
 
 
 def compute_ssim_loss(pred, target, window_size=11):
-    """1 - mean SSIM with an 11^3 box window (reference :88-107)."""
-    C1, C2 = 0.01 ** 2, 0.03 ** 2
-    pad = window_size // 2
-
-    def box(z):
-        return F.avg_pool3d(z, window_size, stride=1, padding=pad)
-
-    mu_p, mu_t = box(pred), box(target)
-    var_p = box(pred * pred) - mu_p * mu_p
-    var_t = box(target * target) - mu_t * mu_t
-    cov = box(pred * target) - mu_p * mu_t
-    ssim = ((2 * mu_p * mu_t + C1) * (2 * cov + C2)) / ((mu_p * mu_p + mu_t * mu_t + C1) * (var_p + var_t + C2))
-    return 1 - ssim.mean()
+    """1 - mean SSIM with a window_size^3 zero-padded box window (reference :88-107), fused HIP kernel."""
+    if not pred.is_cuda:
+        raise RuntimeError("compute_ssim_loss runs on the MI355X HIP path only (no CPU fallback)")
+    return HF.SsimL1LossFn.apply(pred, target, 0.0, 1.0, int(window_size))[2]
 
 
 class DirectRegressionLoss(nn.Module):
@@ -62,6 +54,7 @@ class DirectRegressionLoss(nn.Module):
         self.ssim_weight = ssim_weight
 
     def forward(self, pred, target):
-        l1 = F.l1_loss(pred, target)
-        ssim = compute_ssim_loss(pred, target)
-        return {"total_loss": self.l1_weight * l1 + self.ssim_weight * ssim, "l1_loss": l1, "ssim_loss": ssim}
+        if not pred.is_cuda:
+            raise RuntimeError("DirectRegressionLoss runs on the MI355X HIP path only (no CPU fallback)")
+        out = HF.SsimL1LossFn.apply(pred, target, float(self.l1_weight), float(self.ssim_weight), 11)
+        return {"total_loss": out[0], "l1_loss": out[1], "ssim_loss": out[2]}

@@ -23,8 +23,9 @@ SIGNATURES = {
     "hvc_device_info": (_i, [C.POINTER(_i), C.POINTER(_i), C.c_char_p, _i]),
     "hvc_attention_fwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i] + [_i64] * 12 + [_f, _f, _u64, _i, _p]),
     "hvc_attention_bwd": (_i, [_p] * 10 + [_i] * 5 + [_i64] * 12 + [_f, _f, _u64, _i, _p]),
-    "hvc_gemm": (_i, [_p, _p, _p, _i, _i, _i, _i64, _i64, _i64, _i, _i, _f, _p, _i, _p, _p, _i64, _p, _p, _i64, _i,
-                      _f, _u64, _i, _i, _p]),
+    "hvc_gemm": (_i, [_p, _p, _p, _i, _i, _i, _i64, _i64, _i64, _i, _i, _f, _p, _i, _p, _p, _i64, _p, _p, _i64, _i, _i,
+                      _f, _u64, _p, _i64, _i, _i, _p]),
+    "hvc_gemm_workspace": (_i64, [_i, _i, _i]),
     "hvc_layernorm_fwd": (_i, [_p] * 8 + [_i, _i, _i, _f, _i, _p]),
     "hvc_layernorm_bwd_workspace": (_i64, [_i, _i, _i]),
     "hvc_layernorm_bwd": (_i, [_p] * 14 + [_i, _i, _i, _i, _p]),
@@ -33,6 +34,18 @@ SIGNATURES = {
     "hvc_colsum_workspace": (_i64, [_i, _i]),
     "hvc_colsum": (_i, [_p, _p, _p, _i, _i, _i, _p]),
     "hvc_cast": (_i, [_p, _p, _i64, _i, _i, _p]),
+    "hvc_im2col": (_i, [_p, _p] + [_i] * 12 + [_i64, _i, _p]),
+    "hvc_col2im": (_i, [_p, _p] + [_i] * 12 + [_i64, _i, _p]),
+    "hvc_trilinear_fwd": (_i, [_p, _p] + [_i] * 7 + [_p]),
+    "hvc_trilinear_bwd": (_i, [_p, _p] + [_i] * 7 + [_p]),
+    "hvc_norm_workspace": (_i64, [_i, _i, _i, _i]),
+    "hvc_groupnorm_silu_fwd": (_i, [_p] * 6 + [_i, _i, _i, _i, _f, _i, _p]),
+    "hvc_groupnorm_silu_bwd": (_i, [_p] * 9 + [_i, _i, _i, _i, _i, _p]),
+    "hvc_bn_relu_pool_fwd": (_i, [_p] * 9 + [_i] * 8 + [_f, _f, _i, _p]),
+    "hvc_bn_relu_pool_bwd": (_i, [_p] * 10 + [_i] * 8 + [_i, _p]),
+    "hvc_ssim_l1_workspace": (_i64, [_i, _i, _i, _i]),
+    "hvc_ssim_l1_fwd": (_i, [_p] * 5 + [_i] * 5 + [_f, _f, _p]),
+    "hvc_ssim_l1_bwd": (_i, [_p] * 6 + [_i] * 5 + [_f, _f, _p]),
     "hvc_drr_fwd": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _f, _f, _f, _i, _i, _p]),
     "hvc_drr_bwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _f, _f, _i, _i, _p]),
 }

@@ -345,3 +345,147 @@ class DrrFn(torch.autograd.Function):
 
 def drr_project(vol, axis, *, exp_mode, mu=0.3, out_scale=1.0, clamp_min=float("-inf"), transpose_out=False):
     return DrrFn.apply(vol, axis, exp_mode, mu, out_scale, clamp_min, transpose_out)
+
+
+# --------------------------------------------------------------------------------------------
+# conv stems on channels-last activations, normalisation, resize, loss
+# --------------------------------------------------------------------------------------------
+def conv_weight_2d(weight: torch.Tensor, dtype: torch.dtype, Kp: int) -> torch.Tensor:
+    """(Cout, Cin, *k) parameter -> GEMM operand (Cout, Kp), column = tap * Cin + c; cached per version."""
+    key = (weight._version, _CAST_EPOCH, dtype, Kp)
+    hit = getattr(weight, "_hvc_w2d", None)
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    w = weight.detach()
+    cout, cin = w.shape[0], w.shape[1]
+    w2 = w.reshape(cout, cin, -1).permute(0, 2, 1).reshape(cout, -1)      # (Cout, taps*Cin)
+    if w2.shape[1] != Kp:
+        w2 = torch.nn.functional.pad(w2, (0, Kp - w2.shape[1]))
+    w2 = ops.cast(w2.contiguous(), dtype) if dtype != w2.dtype else w2.contiguous()
+    try:
+        weight._hvc_w2d = (key, w2)
+    except AttributeError:
+        pass
+    return w2
+
+
+class ConvFn(torch.autograd.Function):
+    """Convolution on channels-last x (B, D, H, W, Cin) as im2col + MFMA GEMM (+ bias, + broadcast add of
+    `addvec` (N_tok, Cout), i.e. pos_embed, on the last stem layer).  Output (B, OD, OH, OW, Cout)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, addvec, geom, cdt, out_dtype):
+        xc = _as_cdt(x, cdt)
+        col = ops.im2col(xc, geom)
+        w2d = conv_weight_2d(weight, cdt, geom.Kp)
+        add = None
+        if addvec is not None:
+            add = _f32(addvec).reshape(-1, weight.shape[0])
+        y = ops.gemm(col, w2d, bias=_f32(bias), residual=add, residual_rows=add.shape[0] if add is not None else 0,
+                     out_dtype=out_dtype)
+        ctx.save_for_backward(col, weight)
+        ctx.cfg = (geom, cdt, x.dtype, bias is not None, None if addvec is None else tuple(addvec.shape))
+        return y.view(geom.B, *geom.out, weight.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        col, weight = ctx.saved_tensors
+        geom, cdt, xdt, has_bias, add_shape = ctx.cfg
+        cout = weight.shape[0]
+        dy2 = dy.reshape(geom.M, cout)
+        dyc = _as_cdt(dy2, cdt)
+        db = ops.colsum(dyc) if has_bias and ctx.needs_input_grad[2] else None
+        dw = None
+        if ctx.needs_input_grad[1]:
+            dw2d = ops.gemm(dyc, col, a_kmajor=True, b_kmajor=True, out_dtype=torch.float32)        # (Cout, Kp)
+            taps = geom.taps
+            dw = dw2d[:, :taps * geom.C].reshape(cout, taps, geom.C).permute(0, 2, 1).reshape(weight.shape)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dcol = ops.gemm(dyc, conv_weight_2d(weight, cdt, geom.Kp), b_kmajor=True)                # (M, Kp)
+            dx = ops.col2im(dcol, geom)
+            if dx.dtype != xdt:
+                dx = dx.to(xdt)
+        dadd = None
+        if add_shape is not None and ctx.needs_input_grad[3]:
+            dadd = dy.reshape(geom.B, -1, cout).float().sum(dim=0).reshape(add_shape)
+        return dx, dw, db, dadd, None, None, None
+
+
+class GroupNormSiluFn(torch.autograd.Function):
+    """GroupNorm(G) + SiLU on channels-last (B, ..., C)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, G, eps):
+        shp = x.shape
+        x3 = x.detach().contiguous().view(shp[0], -1, shp[-1])
+        y, stats = ops.groupnorm_silu_fwd(x3, _f32(gamma), _f32(beta), G, eps)
+        ctx.save_for_backward(x3, gamma, beta, stats)
+        ctx.G = G
+        return y.view(shp)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x3, gamma, beta, stats = ctx.saved_tensors
+        dyc = dy.reshape(x3.shape)
+        if dyc.dtype != x3.dtype:
+            dyc = ops.cast(dyc, x3.dtype)
+        dx, dg, db = ops.groupnorm_silu_bwd(x3, dyc, _f32(gamma), _f32(beta), stats, ctx.G)
+        return dx.view(dy.shape), dg, db, None, None
+
+
+class BnReluPoolFn(torch.autograd.Function):
+    """BatchNorm2d + ReLU (+ MaxPool2d) on channels-last (N, H, W, C).  running stats are updated in place."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, pool, training, eps, momentum):
+        xc = x.detach().contiguous()
+        y, amax, stats = ops.bn_relu_pool_fwd(xc, _f32(gamma), _f32(beta), running_mean, running_var, pool, training, eps, momentum)
+        ctx.save_for_backward(xc, gamma, beta, amax, stats)
+        ctx.cfg = (pool, training)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xc, gamma, beta, amax, stats = ctx.saved_tensors
+        pool, training = ctx.cfg
+        dyc = dy if dy.dtype == xc.dtype else ops.cast(dy.contiguous(), xc.dtype)
+        dx, dg, db = ops.bn_relu_pool_bwd(xc, dyc, amax, _f32(gamma), _f32(beta), stats, pool, training)
+        return dx, dg, db, None, None, None, None, None, None
+
+
+class TrilinearFn(torch.autograd.Function):
+    """(B, 1, d, h, w) fp32 -> (B, 1, D, H, W), align_corners=True."""
+
+    @staticmethod
+    def forward(ctx, x, size):
+        B = x.shape[0]
+        ctx.in_size = tuple(x.shape[2:])
+        return ops.trilinear_fwd(_f32(x).view(B, *ctx.in_size), tuple(size)).view(B, 1, *size)
+
+    @staticmethod
+    def backward(ctx, dy):
+        B = dy.shape[0]
+        dx = ops.trilinear_bwd(_f32(dy).view(B, *dy.shape[2:]), ctx.in_size)
+        return dx.view(B, 1, *ctx.in_size), None
+
+
+class SsimL1LossFn(torch.autograd.Function):
+    """(total, l1, ssim_loss) of direct_regression/model_direct.py:118-131 in one fused pass."""
+
+    @staticmethod
+    def forward(ctx, pred, target, l1_w, ssim_w, window):
+        B = pred.shape[0]
+        p = _f32(pred).view(B, *pred.shape[-3:])
+        t = _f32(target).view(B, *target.shape[-3:])
+        out, gmaps = ops.ssim_l1_fwd(p, t, window, l1_w, ssim_w)
+        ctx.save_for_backward(p, t, gmaps)
+        ctx.cfg = (l1_w, ssim_w, window, pred.shape, pred.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        p, t, gmaps = ctx.saved_tensors
+        l1_w, ssim_w, window, shape, dtype = ctx.cfg
+        dp = ops.ssim_l1_bwd(p, t, gmaps, _f32(dout), window, l1_w, ssim_w).view(shape)
+        return (dp if dp.dtype == dtype else dp.to(dtype)), None, None, None, None

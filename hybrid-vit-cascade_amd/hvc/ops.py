@@ -13,6 +13,30 @@ from ._lib import HVC_BF16, HVC_F32, check
 
 _DT = {torch.float32: HVC_F32, torch.bfloat16: HVC_BF16}
 
+# Optional per-call timing (bench.py): when PROFILE is a list, every wrapper brackets its launches
+# with HIP events recorded on the launch stream and appends (name, algorithmic_work, start, end).
+PROFILE = None
+
+
+class _Timed:
+    __slots__ = ("name", "work", "start")
+
+    def __init__(self, name, work):
+        self.name, self.work, self.start = name, work, None
+
+    def __enter__(self):
+        if PROFILE is not None:
+            self.start = torch.cuda.Event(enable_timing=True)
+            self.start.record()
+        return self
+
+    def __exit__(self, *exc):
+        if self.start is not None:
+            end = torch.cuda.Event(enable_timing=True)
+            end.record()
+            PROFILE.append((self.name, self.work, self.start, end))
+        return False
+
 
 def _code(dtype):
     try:
@@ -66,7 +90,8 @@ def attention_fwd(q, k, v, scale, p_drop=0.0, seed=0):
         raise ValueError("attention: q/k/v shape or dtype mismatch")
     o = torch.empty((B, Nq, H, D), dtype=q.dtype, device=q.device)
     lse = torch.empty((B, H, Nq), dtype=torch.float32, device=q.device)
-    check(_lib.load().hvc_attention_fwd(
+    with _Timed("attention_fwd", 4.0 * B * H * Nq * Nk * D):
+      check(_lib.load().hvc_attention_fwd(
         q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse.data_ptr(), B, H, Nq, Nk, D,
         *_bnhd_strides(q), *_bnhd_strides(k), *_bnhd_strides(v), *_bnhd_strides(o),
         float(scale), float(p_drop), int(seed), _code(q.dtype), _stream()), "hvc_attention_fwd")
@@ -94,7 +119,8 @@ def attention_bwd(q, k, v, o, dout, lse, scale, p_drop=0.0, seed=0, dq=None, dk=
         if g.shape != x.shape or any(gs != xs for gs, xs, sz in zip(g.stride(), x.stride(), x.shape) if sz > 1):
             raise ValueError(f"attention_bwd: {n} must have the shape and strides of its primal")
     delta = torch.empty((B, H, Nq), dtype=torch.float32, device=q.device)
-    check(_lib.load().hvc_attention_bwd(
+    with _Timed("attention_bwd", 10.0 * B * H * Nq * Nk * D):
+      check(_lib.load().hvc_attention_bwd(
         q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), dout.data_ptr(), lse.data_ptr(),
         delta.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), B, H, Nq, Nk, D,
         *_bnhd_strides(q), *_bnhd_strides(k), *_bnhd_strides(v), *_bnhd_strides(o),
@@ -122,7 +148,7 @@ def _ld(t):
 
 
 def gemm(a, b, *, a_kmajor=False, b_kmajor=False, alpha=1.0, bias=None, act=ACT_NONE, aux=None, zsave=None,
-         gate=None, residual=None, rows_per_batch=0, p_drop=0.0, seed=0, out_dtype=None, out=None):
+         gate=None, residual=None, residual_rows=0, rows_per_batch=0, p_drop=0.0, seed=0, out_dtype=None, out=None):
     """C[i][j] = sum_k A(i,k) B(j,k) with the fused epilogue of hvc_gemm.
 
     a: (M,K) if not a_kmajor else (K,M);  b: (N,K) if not b_kmajor else (K,N); both 2-D with unit
@@ -146,14 +172,21 @@ def gemm(a, b, *, a_kmajor=False, b_kmajor=False, alpha=1.0, bias=None, act=ACT_
     _f32c(bias, "bias"), _f32c(gate, "gate")
     if zsave is not None and (zsave.shape != (M, N) or zsave.dtype != a.dtype or not _unit_inner(zsave)):
         raise ValueError("gemm: zsave must be (M,N) in the operand dtype")
-    if residual is not None and (residual.dtype != torch.float32 or residual.shape != (M, N) or not _unit_inner(residual)):
-        raise ValueError("gemm: residual must be fp32 (M,N)")
-    check(_lib.load().hvc_gemm(
+    if residual is not None and (residual.dtype != torch.float32 or residual.shape != (residual_rows or M, N) or not _unit_inner(residual)):
+        raise ValueError("gemm: residual must be fp32 (M,N) (or (residual_rows,N))")
+    lib = _lib.load()
+    ws, ws_n = None, 0
+    if bias is None and act == ACT_NONE and gate is None and residual is None and zsave is None and p_drop == 0.0:
+        ws_n = lib.hvc_gemm_workspace(M, N, K)
+        if ws_n > 0:
+            ws = torch.empty((ws_n,), dtype=torch.float32, device=a.device)
+    with _Timed("gemm", 2.0 * M * N * K):
+      check(_lib.load().hvc_gemm(
         a.data_ptr(), b.data_ptr(), out.data_ptr(), M, N, K, _ld(a), _ld(b), _ld(out),
         int(a_kmajor), int(b_kmajor), float(alpha), _ptr(bias), int(act), _ptr(aux), _ptr(zsave),
         _ld(zsave) if zsave is not None else 0, _ptr(gate),
-        _ptr(residual), _ld(residual) if residual is not None else 0, int(rows_per_batch),
-        float(p_drop), int(seed), _code(a.dtype), _code(out_dtype), _stream()), "hvc_gemm")
+        _ptr(residual), _ld(residual) if residual is not None else 0, int(residual_rows), int(rows_per_batch),
+        float(p_drop), int(seed), _ptr(ws), int(ws_n), _code(a.dtype), _code(out_dtype), _stream()), "hvc_gemm")
     return out
 
 
@@ -275,3 +308,151 @@ def drr_bwd(vol, out, dout, axis, *, exp_mode, mu=0.3, out_scale=1.0, clamp_min=
                                   int(exp_mode), float(mu), float(out_scale), float(clamp_min), int(transpose_out),
                                   _code(vol.dtype), _stream()), "hvc_drr_bwd")
     return dvol
+
+
+# --------------------------------------------------------------------------------------------
+# convolution stems (channels-last), normalisation, resize, loss
+# --------------------------------------------------------------------------------------------
+class ConvGeometry:
+    """Geometry of one convolution on channels-last activations (2-D convs use D = KD = 1, PD = 0)."""
+
+    def __init__(self, B, C, src, kernel, stride, pad):
+        self.B, self.C = int(B), int(C)
+        self.src, self.kernel, self.stride, self.pad = tuple(src), tuple(kernel), int(stride), tuple(pad)
+        self.out = tuple((s + 2 * p - k) // self.stride + 1 for s, k, p in zip(self.src, self.kernel, self.pad))
+        self.taps = self.kernel[0] * self.kernel[1] * self.kernel[2]
+        k = self.taps * self.C
+        self.Kp = k if self.C % 8 == 0 else (k + 7) // 8 * 8
+        self.M = self.B * self.out[0] * self.out[1] * self.out[2]
+
+    def args(self):
+        return (self.B, self.C, *self.src, *self.kernel, self.stride, *self.pad, self.Kp)
+
+
+def im2col(x, geom):
+    """x: channels-last (B, D, H, W, C) contiguous -> patch matrix (M, Kp)."""
+    _dev(x)
+    if not x.is_contiguous() or x.shape != (geom.B, *geom.src, geom.C):
+        raise ValueError("im2col: contiguous channels-last (B,D,H,W,C) tensor expected")
+    col = torch.empty((geom.M, geom.Kp), dtype=x.dtype, device=x.device)
+    check(_lib.load().hvc_im2col(x.data_ptr(), col.data_ptr(), *geom.args(), _code(x.dtype), _stream()), "hvc_im2col")
+    return col
+
+
+def col2im(dcol, geom):
+    _dev(dcol)
+    if not dcol.is_contiguous() or dcol.shape != (geom.M, geom.Kp):
+        raise ValueError("col2im: contiguous (M, Kp) matrix expected")
+    dx = torch.empty((geom.B, *geom.src, geom.C), dtype=dcol.dtype, device=dcol.device)
+    check(_lib.load().hvc_col2im(dcol.data_ptr(), dx.data_ptr(), *geom.args(), _code(dcol.dtype), _stream()), "hvc_col2im")
+    return dx
+
+
+def trilinear_fwd(x, size):
+    """x: (B, d, h, w) fp32 contiguous -> (B, D, H, W), align_corners=True."""
+    _dev(x)
+    _f32c(x, "x")
+    B, d, h, w = x.shape
+    y = torch.empty((B, *size), dtype=torch.float32, device=x.device)
+    check(_lib.load().hvc_trilinear_fwd(x.data_ptr(), y.data_ptr(), B, d, h, w, *size, _stream()), "hvc_trilinear_fwd")
+    return y
+
+
+def trilinear_bwd(dy, in_size):
+    _dev(dy)
+    _f32c(dy, "dy")
+    B, D, H, W = dy.shape
+    dx = torch.empty((B, *in_size), dtype=torch.float32, device=dy.device)
+    check(_lib.load().hvc_trilinear_bwd(dy.data_ptr(), dx.data_ptr(), B, *in_size, D, H, W, _stream()), "hvc_trilinear_bwd")
+    return dx
+
+
+def _norm_ws(B, P, C, G, device):
+    n = _lib.load().hvc_norm_workspace(B, P, C, G)
+    return torch.empty((n,), dtype=torch.float32, device=device)
+
+
+def groupnorm_silu_fwd(x, gamma, beta, G, eps=1e-5):
+    """x: (B, P, C) channels-last contiguous.  Returns y, stats (B, G, 2)."""
+    _dev(x, gamma, beta)
+    B, P, Cn = x.shape
+    if not x.is_contiguous():
+        raise ValueError("groupnorm: contiguous (B,P,C) expected")
+    y = torch.empty_like(x)
+    stats = torch.empty((B, G, 2), dtype=torch.float32, device=x.device)
+    ws = _norm_ws(B, P, Cn, G, x.device)
+    check(_lib.load().hvc_groupnorm_silu_fwd(x.data_ptr(), y.data_ptr(), _f32c(gamma, "gamma").data_ptr(), _f32c(beta, "beta").data_ptr(),
+                                             stats.data_ptr(), ws.data_ptr(), B, P, Cn, G, float(eps), _code(x.dtype), _stream()),
+          "hvc_groupnorm_silu_fwd")
+    return y, stats
+
+
+def groupnorm_silu_bwd(x, dy, gamma, beta, stats, G):
+    _dev(x, dy, gamma, beta, stats)
+    B, P, Cn = x.shape
+    dy = dy.contiguous()
+    dx = torch.empty_like(x)
+    dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(beta)
+    ws = _norm_ws(B, P, Cn, G, x.device)
+    check(_lib.load().hvc_groupnorm_silu_bwd(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), gamma.data_ptr(), beta.data_ptr(), stats.data_ptr(),
+                                             dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), B, P, Cn, G, _code(x.dtype), _stream()),
+          "hvc_groupnorm_silu_bwd")
+    return dx, dgamma, dbeta
+
+
+def bn_relu_pool_fwd(x, gamma, beta, running_mean, running_var, pool, training, eps=1e-5, momentum=0.1):
+    """x: (N, H, W, C) channels-last.  pool = (k, s, p) or None.  Returns y (N,HP,WP,C), amax or None, stats (C,2).
+    Updates running_mean / running_var in place when training."""
+    _dev(x, gamma, beta, running_mean, running_var)
+    N, H, W, Cn = x.shape
+    if not x.is_contiguous():
+        raise ValueError("bn_relu_pool: contiguous (N,H,W,C) expected")
+    k, s, p = pool if pool else (1, 1, 0)
+    HP, WP = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    y = torch.empty((N, HP, WP, Cn), dtype=x.dtype, device=x.device)
+    amax = torch.empty((N, HP, WP, Cn), dtype=torch.uint8, device=x.device) if k > 1 else None
+    stats = torch.empty((Cn, 2), dtype=torch.float32, device=x.device)
+    ws = _norm_ws(N, H * W, Cn, Cn, x.device)
+    check(_lib.load().hvc_bn_relu_pool_fwd(x.data_ptr(), y.data_ptr(), _ptr(amax), _f32c(gamma, "gamma").data_ptr(), _f32c(beta, "beta").data_ptr(),
+                                           _ptr(_f32c(running_mean, "running_mean")), _ptr(_f32c(running_var, "running_var")), stats.data_ptr(),
+                                           ws.data_ptr(), N, H, W, Cn, k, s, p, int(training), float(eps), float(momentum), _code(x.dtype), _stream()),
+          "hvc_bn_relu_pool_fwd")
+    return y, amax, stats
+
+
+def bn_relu_pool_bwd(x, dy, amax, gamma, beta, stats, pool, training):
+    _dev(x, dy, amax, gamma, beta, stats)
+    N, H, W, Cn = x.shape
+    k, s, p = pool if pool else (1, 1, 0)
+    dy = dy.contiguous()
+    dx = torch.empty_like(x)
+    dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(beta)
+    ws = _norm_ws(N, H * W, Cn, Cn, x.device)
+    check(_lib.load().hvc_bn_relu_pool_bwd(x.data_ptr(), dy.data_ptr(), _ptr(amax), dx.data_ptr(), gamma.data_ptr(), beta.data_ptr(), stats.data_ptr(),
+                                           dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), N, H, W, Cn, k, s, p, int(training), _code(x.dtype),
+                                           _stream()), "hvc_bn_relu_pool_bwd")
+    return dx, dgamma, dbeta
+
+
+def ssim_l1_fwd(pred, target, window=11, l1_w=1.0, ssim_w=0.5):
+    """pred/target: (B, D, H, W) fp32 contiguous.  Returns out3 (total, l1, ssim_loss) and the saved derivative maps."""
+    _dev(pred, target)
+    _f32c(pred, "pred"), _f32c(target, "target")
+    B, D, H, W = pred.shape
+    lib = _lib.load()
+    ws = torch.empty((lib.hvc_ssim_l1_workspace(B, D, H, W),), dtype=torch.float32, device=pred.device)
+    gmaps = torch.empty((3, B, D, H, W), dtype=torch.float32, device=pred.device)
+    out = torch.empty((3,), dtype=torch.float32, device=pred.device)
+    check(lib.hvc_ssim_l1_fwd(pred.data_ptr(), target.data_ptr(), out.data_ptr(), gmaps.data_ptr(), ws.data_ptr(), B, D, H, W, int(window),
+                              float(l1_w), float(ssim_w), _stream()), "hvc_ssim_l1_fwd")
+    return out, gmaps
+
+
+def ssim_l1_bwd(pred, target, gmaps, gscale, window=11, l1_w=1.0, ssim_w=0.5):
+    _dev(pred, target, gmaps, gscale)
+    B, D, H, W = pred.shape
+    ws = torch.empty((6 * pred.numel(),), dtype=torch.float32, device=pred.device)
+    dpred = torch.empty_like(pred)
+    check(_lib.load().hvc_ssim_l1_bwd(pred.data_ptr(), target.data_ptr(), gmaps.data_ptr(), _ptr(_f32c(gscale, "gscale")), dpred.data_ptr(),
+                                      ws.data_ptr(), B, D, H, W, int(window), float(l1_w), float(ssim_w), _stream()), "hvc_ssim_l1_bwd")
+    return dpred

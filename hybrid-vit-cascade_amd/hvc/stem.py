@@ -1,41 +1,74 @@
 """Stem / head seams of the hot path: the 3-D voxel-embed stem that turns
 a volume into tokens, the LN + Linear(C,1) head with the trilinear upsample, and the 2-D X-ray CNN
-stem.  Every function here is the single place where that stage is dispatched, so a stage moves
-from its interim backend to its HIP kernel without touching the module classes.
+stem.  The module classes keep the reference's nn.Sequential containers (for parameter names and
+initialisation); these functions walk the containers and run every layer on the HIP kernels, with
+activations held CHANNELS-LAST so that each convolution is im2col + MFMA GEMM and the last stem
+layer's output is already the (B, N, C) token matrix.
 
-Backend status is recorded in STAGE_BACKEND (reported by bench.py and DESIGN.md): "hip" = hand-written
-gfx950 kernel through the C ABI; "miopen" = interim torch op on the GPU (MIOpen / ATen HIP), to be
-replaced per the round plan in DESIGN.md.
+STAGE_BACKEND records what executes each stage (reported by bench.py): "hip" = hand-written gfx950
+kernel through the C ABI; "aten" = a plain torch op on the GPU used as glue.
 """
 import torch
-import torch.nn.functional as F
+import torch.nn as nn
 
 from . import functional as HF
+from . import ops
 
 STAGE_BACKEND = {
-    "voxel_embed_conv3d": "miopen",
-    "voxel_embed_groupnorm_silu": "miopen",
-    "tokens_pos_embed": "aten",
+    "voxel_embed_conv3d": "hip (im2col + MFMA GEMM)",
+    "voxel_embed_groupnorm_silu": "hip",
+    "tokens_pos_embed": "hip (GEMM epilogue)",
     "head_layernorm": "hip",
     "head_proj": "hip",
-    "trilinear_upsample": "aten",
-    "xray_conv2d": "miopen",
-    "xray_batchnorm_relu_pool": "miopen",
+    "trilinear_upsample": "hip",
+    "xray_conv2d": "hip (im2col + MFMA GEMM)",
+    "xray_batchnorm_relu_pool": "hip",
+    "xray_view_mean_gap": "aten",
+    "ssim_l1_loss": "hip",
 }
 
 
 def _require_gpu(t):
     if not t.is_cuda:
-        raise RuntimeError("the HVC hot path runs on the MI355X HIP device only (got a CPU tensor)")
+        raise RuntimeError("the HVC hot path runs on the MI355X HIP device only (got a CPU tensor; there is no CPU fallback)")
+
+
+def _channels_last(x):
+    """(B, C, *spatial) -> (B, *spatial, C); free when C == 1."""
+    if x.shape[1] == 1:
+        return x.reshape(x.shape[0], *x.shape[2:], 1)
+    perm = (0, *range(2, x.dim()), 1)
+    return x.permute(*perm).contiguous()
 
 
 def voxel_tokens(voxel_embed, x, pos_embed):
     """(B,Cin,D,H,W) -> (B,N,C) fp32 tokens, n = (d*H'+h)*W'+w, + pos_embed
     (reference models/hybrid_vit_backbone.py:252-258)."""
     _require_gpu(x)
-    with torch.autocast("cuda", enabled=False):     # interim MIOpen stage runs fp32 (its bf16 3-D conv is unreliable here)
-        h = voxel_embed(x.float())
-    return h.flatten(2).transpose(1, 2) + pos_embed
+    cdt = HF.compute_dtype(x)
+    h = _channels_last(x)                                   # (B, D, H, W, Cin)
+    layers = list(voxel_embed)
+    i = 0
+    fused_pos = False
+    while i < len(layers):
+        layer = layers[i]
+        if isinstance(layer, nn.Conv3d):
+            last = i == len(layers) - 1
+            geom = ops.ConvGeometry(h.shape[0], layer.in_channels, h.shape[1:4], layer.kernel_size, layer.stride[0], layer.padding)
+            h = HF.ConvFn.apply(h, layer.weight, layer.bias, pos_embed if last else None, geom, cdt,
+                                torch.float32 if last else cdt)
+            fused_pos = last
+            i += 1
+        elif isinstance(layer, nn.GroupNorm):
+            assert isinstance(layers[i + 1], nn.SiLU)
+            h = HF.GroupNormSiluFn.apply(h, layer.weight, layer.bias, layer.num_groups, layer.eps)
+            i += 2
+        else:
+            raise RuntimeError(f"unexpected layer in voxel_embed: {type(layer).__name__}")
+    tokens = h.reshape(h.shape[0], -1, h.shape[-1])
+    if not fused_pos:                                       # stem that ends in GN+SiLU (256^3 geometry)
+        tokens = tokens.float() + pos_embed
+    return tokens
 
 
 def token_head(tokens, norm, output_proj, grid):
@@ -43,16 +76,44 @@ def token_head(tokens, norm, output_proj, grid):
     B, N, Cn = tokens.shape
     h = HF.layer_norm(tokens, norm.weight, norm.bias, out_dtype=torch.float32)
     y = HF.linear(h, output_proj.weight, output_proj.bias, torch.float32, torch.float32)    # (B,N,1)
-    return y.transpose(1, 2).reshape(B, 1, *grid)
+    return y.reshape(B, 1, *grid)
 
 
 def upsample_trilinear(vol, size):
     """F.interpolate(trilinear, align_corners=True)   (reference models/hybrid_vit_backbone.py:272)."""
-    return F.interpolate(vol, size=tuple(size), mode="trilinear", align_corners=True)
+    return HF.TrilinearFn.apply(vol, tuple(size))
 
 
 def xray_encoder(encoder, xrays_flat):
-    """Conv/BN/ReLU/MaxPool stack on (B*V,1,H,W)   (reference models/diagnostic_losses.py:82-96)."""
+    """Conv / BN / ReLU / MaxPool stack on (B*V,1,H,W) (reference models/diagnostic_losses.py:82-96).
+    Returns the feature map channels-last: (B*V, H', W', E)."""
     _require_gpu(xrays_flat)
-    with torch.autocast("cuda", enabled=False):
-        return encoder(xrays_flat.float())
+    cdt = HF.compute_dtype(xrays_flat)
+    h = _channels_last(xrays_flat)                          # (N, H, W, Cin)
+    layers = list(encoder)
+    i = 0
+    while i < len(layers):
+        layer = layers[i]
+        if isinstance(layer, nn.Conv2d):
+            geom = ops.ConvGeometry(h.shape[0], layer.in_channels, (1, h.shape[1], h.shape[2]), (1, *layer.kernel_size),
+                                    layer.stride[0], (0, *layer.padding))
+            y = HF.ConvFn.apply(h.reshape(h.shape[0], 1, *h.shape[1:]), layer.weight, layer.bias, None, geom, cdt, cdt)
+            h = y.reshape(y.shape[0], y.shape[2], y.shape[3], y.shape[4])
+            i += 1
+        elif isinstance(layer, nn.BatchNorm2d):
+            assert isinstance(layers[i + 1], nn.ReLU)
+            pool = None
+            step = 2
+            if i + 2 < len(layers) and isinstance(layers[i + 2], nn.MaxPool2d):
+                mp = layers[i + 2]
+                pool = (int(mp.kernel_size), int(mp.stride), int(mp.padding))
+                step = 3
+            training = layer.training
+            h = HF.BnReluPoolFn.apply(h, layer.weight, layer.bias, layer.running_mean, layer.running_var, pool, training,
+                                      layer.eps, layer.momentum if layer.momentum is not None else 0.1)
+            if training:
+                layer.num_batches_tracked += 1
+            i += step
+        else:
+            raise RuntimeError(f"unexpected layer in xray encoder: {type(layer).__name__}")
+    return h

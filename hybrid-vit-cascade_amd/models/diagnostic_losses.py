@@ -48,12 +48,14 @@ class XrayConditioningModule(nn.Module):
 
     def forward(self, xrays: torch.Tensor, t: torch.Tensor):
         B, V = xrays.shape[0], xrays.shape[1]
+        # channels-last feature map (B*V, H', W', E) straight out of the HIP stem
         if V > 1:
-            feats = HS.xray_encoder(self.encoder, xrays.reshape(B * V, *xrays.shape[2:]))
-            feats = feats.view(B, V, *feats.shape[1:]).mean(dim=1)
+            f = HS.xray_encoder(self.encoder, xrays.reshape(B * V, *xrays.shape[2:]))
+            f = f.view(B, V, *f.shape[1:]).float().mean(dim=1)             # average the views (reference :126)
         else:
-            feats = HS.xray_encoder(self.encoder, xrays[:, 0])
-        pooled = feats.float().mean(dim=[-2, -1])
+            f = HS.xray_encoder(self.encoder, xrays[:, 0]).float()
+        pooled = f.mean(dim=(1, 2))                                        # global average pool (reference :131)
+        feats = f.permute(0, 3, 1, 2)     # (B, E, H', W') view; .flatten(2).transpose(1, 2) of it is copy-free
         f32 = torch.float32
         xray_context = HF.linear(pooled, self.to_cond.weight, self.to_cond.bias, f32, f32)
         te = HF.linear(t.float(), self.time_mlp[0].weight, self.time_mlp[0].bias, f32, f32)

@@ -83,14 +83,22 @@ int hvc_attention_bwd(const void* q, const void* k, const void* v, const void* o
  *        | 2 multiply by GELU'(aux)  (backward of 1; aux = saved pre-activation)
  *   zsave: optional [M][N] copy of z in in_dtype with leading dimension ldz (kept for the gate gradient);
  *   bias: [N] fp32 or NULL;  gate: [M / rows_per_batch][N] fp32 or NULL;
- *   residual: [M][N] fp32 with leading dimension ldr, or NULL.
+ *   residual: [M][N] fp32 with leading dimension ldr, or NULL; with residual_rows > 0 it has that many
+ *   rows and row i adds residual[i % residual_rows] (the pos_embed add of
+ *   models/hybrid_vit_backbone.py:258 fused into the last stem convolution).
  *   in_dtype / out_dtype: (BF16,BF16), (BF16,F32) or (F32,F32).
  * ---------------------------------------------------------------------------------------------- */
 int hvc_gemm(const void* A, const void* B, void* C, int M, int N, int K,
              int64_t lda, int64_t ldb, int64_t ldc, int a_kmajor, int b_kmajor, float alpha,
              const float* bias, int act, void* aux, void* zsave, int64_t ldz,
-             const float* gate, const float* residual, int64_t ldr, int rows_per_batch,
-             float p_drop, uint64_t seed, int in_dtype, int out_dtype, void* stream);
+             const float* gate, const float* residual, int64_t ldr, int residual_rows, int rows_per_batch,
+             float p_drop, uint64_t seed, float* workspace, int64_t workspace_floats,
+             int in_dtype, int out_dtype, void* stream);
+/* Floats of split-K scratch worth passing as `workspace` for this shape (0 = none needed).  With a
+ * workspace and a plain epilogue (alpha only) a small-output / deep-contraction product -- every
+ * weight gradient dW = dy^T x -- is sliced over workgroups along K into fp32 slabs that a second
+ * kernel sums in a fixed order (bitwise reproducible).  workspace may be NULL. */
+int64_t hvc_gemm_workspace(int M, int N, int K);
 
 /* ------------------------------------------------------------------------------------------------
  * LayerNorm (+ optional AdaLN modulate y = ln(x) * (1 + scale_b) + shift_b).
@@ -153,6 +161,64 @@ int hvc_drr_fwd(const void* vol, void* out, int B, int D, int H, int W, int axis
 int hvc_drr_bwd(const void* vol, const void* out, const void* dout, void* dvol,
                 int B, int D, int H, int W, int axis, int exp_mode, float mu, float out_scale,
                 float clamp_min, int transpose_out, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Convolution stems as im2col + hvc_gemm on CHANNELS-LAST activations [B][D][H][W][C] (2-D: D = 1).
+ * Replaces nn.Conv3d(k3, s1|s2, p1) at models/hybrid_vit_backbone.py:195-210 and
+ * nn.Conv2d(k7 s2 p3 / k3 s1 p1) at models/diagnostic_losses.py:82,87,92, forward and backward:
+ *   y  = hvc_gemm(col, W2d[Cout][taps*C], bias)             col = hvc_im2col(x)
+ *   dx = hvc_col2im(hvc_gemm(dy, W2d, b_kmajor))            (gather form, deterministic)
+ *   dW = hvc_gemm(dy, col, a_kmajor, b_kmajor)              (split-K)
+ * col is [B*OD*OH*OW][Kp], column index = tap*C + c, tap = (kd*KH + kh)*KW + kw; Kp = taps*C when
+ * C % 8 == 0, else taps*C rounded up to a multiple of 8 (zero filled).  O = (S + 2P - K)/stride + 1.
+ * ---------------------------------------------------------------------------------------------- */
+int hvc_im2col(const void* src, void* col, int B, int C, int SD, int SH, int SW, int KD, int KH, int KW,
+               int stride, int PD, int PH, int PW, int64_t Kp, int dtype, void* stream);
+int hvc_col2im(const void* dcol, void* dsrc, int B, int C, int SD, int SH, int SW, int KD, int KH, int KW,
+               int stride, int PD, int PH, int PW, int64_t Kp, int dtype, void* stream);
+
+/* Trilinear resize of single-channel fp32 volumes [B][d][h][w] -> [B][D][H][W], align_corners=True
+ * (F.interpolate at models/hybrid_vit_backbone.py:272) and its adjoint. */
+int hvc_trilinear_fwd(const float* src, float* dst, int B, int d, int h, int w, int D, int H, int W, void* stream);
+int hvc_trilinear_bwd(const float* dout, float* dsrc, int B, int d, int h, int w, int D, int H, int W, void* stream);
+
+/* Floats of scratch for the four normalisation calls below. */
+int64_t hvc_norm_workspace(int B, int P, int C, int G);
+
+/* GroupNorm(G, C) + SiLU on channels-last x[B][P][C] (nn.GroupNorm + nn.SiLU at
+ * models/hybrid_vit_backbone.py:199-200).  stats: [B][G][2] (mean, rstd), written by fwd, read by bwd.
+ * C in {8,16,32,64,128,256,512}. */
+int hvc_groupnorm_silu_fwd(const void* x, void* y, const float* gamma, const float* beta, float* stats,
+                           float* workspace, int B, int P, int C, int G, float eps, int dtype, void* stream);
+int hvc_groupnorm_silu_bwd(const void* x, const void* dy, void* dx, const float* gamma, const float* beta,
+                           const float* stats, float* dgamma, float* dbeta, float* workspace,
+                           int B, int P, int C, int G, int dtype, void* stream);
+
+/* BatchNorm2d + ReLU + MaxPool2d(k, s, p) on channels-last x[N][H][W][C] (models/diagnostic_losses.py:83-85,
+ * 88-90, 93-94; k = 1 for the last, pool-less stage).  training: batch statistics, running_mean/var
+ * updated in place with `momentum` (unbiased variance), else running statistics.  y: [N][HP][WP][C];
+ * amax: [N][HP][WP][C] bytes (window-local arg-max, needed when k > 1); stats: [C][2].
+ * workspace: hvc_norm_workspace(N, H*W, C, C) floats. */
+int hvc_bn_relu_pool_fwd(const void* x, void* y, uint8_t* amax, const float* gamma, const float* beta,
+                         float* running_mean, float* running_var, float* stats, float* workspace,
+                         int N, int H, int W, int C, int k, int s, int p, int training, float eps,
+                         float momentum, int dtype, void* stream);
+int hvc_bn_relu_pool_bwd(const void* x, const void* dy, const uint8_t* amax, void* dx, const float* gamma,
+                         const float* beta, const float* stats, float* dgamma, float* dbeta,
+                         float* workspace, int N, int H, int W, int C, int k, int s, int p, int training,
+                         int dtype, void* stream);
+
+/* Fused training loss  l1_w * mean|p - t| + ssim_w * (1 - mean SSIM_window^3(p, t))  on fp32 volumes
+ * [B][D][H][W] (direct_regression/model_direct.py:88-131; window 11, zero padded, divisor window^3).
+ * fwd: out3 = (total, l1, ssim_loss); gmaps [3][B*D*H*W] is kept for bwd;
+ *      workspace: hvc_ssim_l1_workspace floats.  bwd: dpred = sum_i gscale[i] * d out3[i] / dpred with
+ *      gscale a device [3] vector (NULL = (1,0,0)); workspace: 6 * B*D*H*W floats. */
+int64_t hvc_ssim_l1_workspace(int B, int D, int H, int W);
+int hvc_ssim_l1_fwd(const float* pred, const float* target, float* out3, float* gmaps, float* workspace,
+                    int B, int D, int H, int W, int window, float l1_w, float ssim_w, void* stream);
+int hvc_ssim_l1_bwd(const float* pred, const float* target, const float* gmaps, const float* gscale,
+                    float* dpred, float* workspace, int B, int D, int H, int W, int window, float l1_w,
+                    float ssim_w, void* stream);
 
 #ifdef __cplusplus
 }

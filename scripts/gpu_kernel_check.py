@@ -171,6 +171,133 @@ drr_case(2, 64, 64, 64, torch.float32)
 drr_case(1, 9, 7, 5, torch.float32)
 drr_case(2, 32, 32, 32, torch.bfloat16)
 
+# ---- conv stems / norms / resize / loss vs torch fp64 on the CPU ----
+import torch.nn.functional as F
+from hvc import functional as HF
+
+def conv_case(dims, B, Cin, Cout, k, stride, pad, S, dtype):
+    g = torch.Generator().manual_seed(Cin * 100 + Cout + S)
+    sp = (S,) * dims
+    x = torch.randn(B, Cin, *sp, generator=g)
+    w = torch.randn(Cout, Cin, *((k,) * dims), generator=g) / (Cin * k ** dims) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    xr, wr, br = (t.to(dtype).double().requires_grad_(True) for t in (x, w, b))
+    conv = F.conv3d if dims == 3 else F.conv2d
+    y_ref = conv(xr, wr, br, stride=stride, padding=pad)
+    dy = torch.randn(y_ref.shape, generator=g)
+    y_ref.backward(dy.to(dtype).double())
+    xd = x.to(dev).to(dtype).requires_grad_(True)
+    wd = w.to(dev).to(dtype).float().requires_grad_(True)
+    bd = b.to(dev).to(dtype).float().requires_grad_(True)
+    perm = (0, *range(2, 2 + dims), 1)
+    x_cl = xd.permute(*perm).contiguous()
+    if dims == 2:
+        x_cl = x_cl.reshape(B, 1, S, S, Cin)
+        geom = ops.ConvGeometry(B, Cin, (1, S, S), (1, k, k), stride, (0, pad, pad))
+    else:
+        geom = ops.ConvGeometry(B, Cin, sp, (k,) * 3, stride, (pad,) * 3)
+    y = HF.ConvFn.apply(x_cl, wd, bd, None, geom, dtype, dtype)          # (B, OD, OH, OW, Cout)
+    y_nc = y.permute(0, 4, 1, 2, 3) if dims == 3 else y[:, 0].permute(0, 3, 1, 2)
+    tol = 2e-2 if dtype == torch.bfloat16 else 1e-4
+    tag = f"conv{dims}d B{B} {Cin}->{Cout} k{k} s{stride} S{S} {str(dtype)[6:]}"
+    report(tag + " y", rel(y_nc.cpu(), y_ref), tol)
+    dyd = dy.to(dev).to(dtype)
+    dy_cl = dyd.permute(0, 2, 3, 4, 1) if dims == 3 else dyd.permute(0, 2, 3, 1).unsqueeze(1)
+    (y.float() * dy_cl.float()).sum().backward()
+    report(tag + " dx", rel(xd.grad.cpu(), xr.grad), tol)
+    report(tag + " dw", rel(wd.grad.cpu(), wr.grad), tol)
+    report(tag + " db", rel(bd.grad.cpu(), br.grad), tol)
+
+for dtype in (torch.float32, torch.bfloat16):
+    conv_case(3, 2, 1, 16, 3, 2, 1, 16, dtype)
+    conv_case(3, 1, 16, 32, 3, 2, 1, 12, dtype)
+    conv_case(3, 2, 32, 64, 3, 1, 1, 8, dtype)
+    conv_case(2, 2, 1, 64, 7, 2, 3, 64, dtype)
+    conv_case(2, 2, 64, 128, 3, 1, 1, 16, dtype)
+
+def gn_case(B, P, Cn, G, dtype):
+    g = torch.Generator().manual_seed(Cn + P)
+    x = torch.randn(B, P, Cn, generator=g) * 2 + 0.3
+    gam, bet = torch.randn(Cn, generator=g), torch.randn(Cn, generator=g)
+    xr = x.to(dtype).double().requires_grad_(True); gr = gam.double().requires_grad_(True); br = bet.double().requires_grad_(True)
+    y_ref = F.silu(F.group_norm(xr.transpose(1, 2), G, gr, br, 1e-5)).transpose(1, 2)
+    dy = torch.randn(B, P, Cn, generator=g)
+    y_ref.backward(dy.to(dtype).double())
+    xd = x.to(dev).to(dtype).requires_grad_(True); gd = gam.to(dev).requires_grad_(True); bd = bet.to(dev).requires_grad_(True)
+    y = HF.GroupNormSiluFn.apply(xd, gd, bd, G, 1e-5)
+    y.backward(dy.to(dev).to(dtype))
+    tol = 2e-2 if dtype == torch.bfloat16 else 1e-4
+    tag = f"gn+silu B{B} P{P} C{Cn} G{G} {str(dtype)[6:]}"
+    report(tag + " y", rel(y.cpu(), y_ref), tol)
+    report(tag + " dx", rel(xd.grad.cpu(), xr.grad), tol)
+    report(tag + " dgamma", rel(gd.grad.cpu(), gr.grad), tol)
+    report(tag + " dbeta", rel(bd.grad.cpu(), br.grad), tol)
+
+for dtype in (torch.float32, torch.bfloat16):
+    gn_case(2, 4096, 64, 8, dtype)
+    gn_case(3, 100, 16, 8, dtype)
+    gn_case(1, 700, 128, 8, dtype)
+
+def bn_case(N, H, Cn, pool, training, dtype):
+    g = torch.Generator().manual_seed(Cn + H + int(training))
+    x = torch.randn(N, Cn, H, H, generator=g) * 1.5 + 0.2
+    gam, bet = torch.rand(Cn, generator=g) + 0.5, torch.randn(Cn, generator=g) * 0.3
+    rm, rv = torch.randn(Cn, generator=g) * 0.1, torch.rand(Cn, generator=g) + 0.5
+    xr = x.to(dtype).double().requires_grad_(True); gr = gam.double().requires_grad_(True); br = bet.double().requires_grad_(True)
+    rm_r, rv_r = rm.double().clone(), rv.double().clone()
+    y_ref = F.relu(F.batch_norm(xr, rm_r, rv_r, gr, br, training, 0.1, 1e-5))
+    if pool: y_ref = F.max_pool2d(y_ref, *pool)
+    dy = torch.randn(y_ref.shape, generator=g)
+    y_ref.backward(dy.to(dtype).double())
+    xd = x.to(dev).to(dtype).permute(0, 2, 3, 1).contiguous().requires_grad_(True)
+    gd = gam.to(dev).requires_grad_(True); bd = bet.to(dev).requires_grad_(True)
+    rmd, rvd = rm.to(dev).clone(), rv.to(dev).clone()
+    y = HF.BnReluPoolFn.apply(xd, gd, bd, rmd, rvd, pool, training, 1e-5, 0.1)
+    y.backward(dy.to(dev).to(dtype).permute(0, 2, 3, 1).contiguous())
+    tol = 2e-2 if dtype == torch.bfloat16 else 1e-4
+    tag = f"bn+relu+pool N{N} H{H} C{Cn} pool{pool} train{int(training)} {str(dtype)[6:]}"
+    report(tag + " y", rel(y.permute(0, 3, 1, 2).cpu(), y_ref), tol)
+    report(tag + " dx", rel(xd.grad.permute(0, 3, 1, 2).cpu(), xr.grad), 3 * tol)
+    report(tag + " dgamma", rel(gd.grad.cpu(), gr.grad), 3 * tol)
+    report(tag + " dbeta", rel(bd.grad.cpu(), br.grad), 3 * tol)
+    if training:
+        report(tag + " running_mean", rel(rmd.cpu(), rm_r), 1e-3 if dtype == torch.bfloat16 else 1e-5)
+        report(tag + " running_var", rel(rvd.cpu(), rv_r), 1e-3 if dtype == torch.bfloat16 else 1e-5)
+
+for dtype in (torch.float32, torch.bfloat16):
+    for training in (True, False):
+        bn_case(4, 32, 64, (3, 2, 1), training, dtype)
+        bn_case(2, 16, 128, (2, 2, 0), training, dtype)
+        bn_case(2, 8, 32, None, training, dtype)
+
+for (B, ins, outs) in ((2, (4, 4, 4), (16, 16, 16)), (1, (16, 8, 8), (64, 32, 32)), (1, (5, 3, 2), (7, 9, 4)), (1, (8, 8, 8), (8, 8, 8))):
+    g = torch.Generator().manual_seed(sum(ins))
+    x = torch.randn(B, 1, *ins, generator=g)
+    xr = x.double().requires_grad_(True)
+    y_ref = F.interpolate(xr, size=outs, mode="trilinear", align_corners=True)
+    dy = torch.randn(y_ref.shape, generator=g)
+    y_ref.backward(dy.double())
+    xd = x.to(dev).requires_grad_(True)
+    y = HF.TrilinearFn.apply(xd, outs)
+    y.backward(dy.to(dev))
+    report(f"trilinear {ins}->{outs} y", rel(y.cpu(), y_ref), 1e-5)
+    report(f"trilinear {ins}->{outs} dx", rel(xd.grad.cpu(), xr.grad), 1e-5)
+
+sys.path.insert(0, ROOT)
+from oracle import hvc_oracle as O
+for shape in ((2, 1, 16, 16, 16), (1, 1, 24, 20, 28), (1, 1, 11, 12, 13)):
+    g = torch.Generator().manual_seed(sum(shape))
+    p = torch.rand(*shape, generator=g) * 2 - 1; t = torch.rand(*shape, generator=g) * 2 - 1
+    pr = p.double().requires_grad_(True)
+    ref = O.direct_regression_loss(pr, t.double())
+    (ref["total_loss"] + 0.3 * ref["l1_loss"] - 0.2 * ref["ssim_loss"]).backward()
+    pd = p.to(dev).requires_grad_(True)
+    out = HF.SsimL1LossFn.apply(pd, t.to(dev), 1.0, 0.5, 11)
+    (out[0] + 0.3 * out[1] - 0.2 * out[2]).backward()
+    report(f"ssim+l1 {shape} total", abs(out[0].item() - ref["total_loss"].item()) / abs(ref["total_loss"].item()), 1e-5)
+    report(f"ssim+l1 {shape} ssim", abs(out[2].item() - ref["ssim_loss"].item()) / abs(ref["ssim_loss"].item()), 1e-5)
+    report(f"ssim+l1 {shape} dpred", rel(pd.grad.cpu(), pr.grad), 1e-4)
+
 # ---- timing ----
 def timeit(fn, n=10):
     fn(); torch.cuda.synchronize()
@@ -202,6 +329,18 @@ if os.environ.get("HVC_TIME", "1") == "1":
     for ax in (0, 2):
         t = timeit(lambda: ops.drr_fwd(vol, ax, exp_mode=True, clamp_min=1e-6), 10)
         print(f"drr fwd axis{ax} 2x256^3 f32: {t*1e6:.1f} us {vol.numel()*4/t/1e9:.0f} GB/s", flush=True)
+
+if os.environ.get("HVC_TIME", "1") == "1":
+    p = torch.rand(2, 1, 128, 128, 128, device=dev); t = torch.rand_like(p)
+    tt = timeit(lambda: HF.SsimL1LossFn.apply(p, t, 1.0, 0.5, 11), 5)
+    print(f"ssim+l1 fwd 2x128^3: {tt*1e3:.3f} ms", flush=True)
+    for (B, Cin, Cout, S, st) in ((2, 64, 128, 64, 2), (2, 128, 256, 32, 1)):
+        x = torch.randn(B, S, S, S, Cin, device=dev, dtype=torch.bfloat16)
+        w = torch.randn(Cout, Cin, 3, 3, 3, device=dev)
+        geom = ops.ConvGeometry(B, Cin, (S, S, S), (3, 3, 3), st, (1, 1, 1))
+        tt = timeit(lambda: HF.ConvFn.apply(x, w, None, None, geom, torch.bfloat16, torch.bfloat16), 5)
+        fl = 2.0 * geom.M * Cout * Cin * 27
+        print(f"conv3d fwd bf16 B{B} {Cin}->{Cout} S{S} s{st}: {tt*1e3:.3f} ms {fl/tt/1e12:.1f} TF/s", flush=True)
 
 print("FAILED:" if fails else "ALL OK", fails)
 sys.exit(1 if fails else 0)
