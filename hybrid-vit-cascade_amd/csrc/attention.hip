@@ -9,12 +9,15 @@
 // kernels read q,k,v straight out of the packed qkv / kv projection outputs and write o in
 // (B,N,h*d) order, which is what the reference's transpose(1,2).reshape produces.
 //
-// Work decomposition (all kernels: 256 threads = 4 waves, one wave per SIMD):
+// Work decomposition (all kernels: 256 threads = 4 waves, <= 256 registers so that 2-3 workgroups
+// share a CU and one wave's softmax VALU work overlaps another wave's MFMAs):
 //   fwd    : workgroup = 128 query rows of one (b,h); wave = 32 rows; loop over 64-key tiles
 //            staged in LDS (double buffered, register-staged global loads issued one tile ahead).
 //            S^T = K Q^T (key rows in registers, query on the lane) so max / sum / rescale are
 //            per-lane scalars; P feeds the PV product straight from the accumulators
 //            (accumulator-as-B-operand) and V is consumed through ds_read_b64_tr_b16.
+//            The running max is only raised (and O, l rescaled) when some row's tile max exceeds it
+//            by more than 2^kRescaleLog2 -- a wave-uniform, rarely taken branch.
 //   bwd dQ : same decomposition; recomputes S^T and dP^T = V dO^T, dQ += dS K (K via tr read).
 //   bwd dKV: workgroup = 128 keys of one (b,h); wave = 32 keys held in registers; loop over
 //            64-query tiles (Q, dO in LDS, read row-wise for S / dP and transposed for dV / dK).
@@ -29,8 +32,22 @@ namespace {
 
 constexpr int kKT = 64;     // keys (or queries, in dKV) per LDS tile
 constexpr int kQB = 128;    // rows per workgroup
+constexpr float kRescaleLog2 = 6.f;   // deferred running-max update: P stays <= 2^6 between rescales
 
-template <typename T, int D>
+// 8 elements of row n (zeros when n >= nrows).  VEC: one clamped 16-byte load + select (no branch).
+template <typename T, bool VEC>
+__device__ __forceinline__ Chunk8<T> load_row_chunk(const T* base, int64_t sn, int n, int nrows, int col) {
+    if constexpr (VEC) {
+        const int nc = n < nrows ? n : nrows - 1;
+        Chunk8<T> c = load_chunk<T>(base + (int64_t)nc * sn + col, 8, true);
+        if (n >= nrows) c = zero_chunk<T>();
+        return c;
+    } else {
+        return load_chunk<T>(base + (int64_t)n * sn + col, n < nrows ? 8 : 0, false);
+    }
+}
+
+template <typename T, int D, bool VEC>
 struct TileLoader {
     static constexpr int NS = NSplit<T>::value;
     static constexpr int CPR = D / 8;                  // 16-byte chunks per row
@@ -38,13 +55,12 @@ struct TileLoader {
     static constexpr int CPT = CHUNKS / 256;           // chunks per thread
     Chunk8<T> reg[CPT];
 
-    __device__ __forceinline__ void issue(const T* base, int64_t sn, int row0, int nrows, bool vec, int tid) {
+    __device__ __forceinline__ void issue(const T* base, int64_t sn, int row0, int nrows, int tid) {
 #pragma unroll
         for (int i = 0; i < CPT; ++i) {
             int c = tid + 256 * i;
             int row = c / CPR, ch = c % CPR;
-            int n = row0 + row;
-            reg[i] = load_chunk<T>(base + (int64_t)n * sn + ch * 8, n < nrows ? 8 : 0, vec);
+            reg[i] = load_row_chunk<T, VEC>(base, sn, row0 + row, nrows, ch * 8);
         }
     }
     // images: NS consecutive tiles of kKT*D bf16
@@ -61,6 +77,20 @@ struct TileLoader {
     }
 };
 
+// ---- attention-probability dropout ------------------------------------------------------------------
+// keep(b,h,q,k) = lot16(hash(rowkey(b,h,q) + (k >> 1) * C), k & 1) >= thresh.  rowkey is one 32-bit word
+// per query row (computed once per lane, or once per LDS tile row in the dKV kernel), so the
+// per-element cost is one multiply-xorshift round shared by two keys plus a compare and a select.
+__device__ __forceinline__ uint32_t drop_rowkey(const AttnArgs& a, int bh, int q) {
+    return mix32(((uint32_t)(bh * a.Nq + q) * 0x9E3779B1u) ^ a.seed_lo) ^ a.seed_hi;
+}
+__device__ __forceinline__ uint32_t drop_bits(uint32_t rowkey, uint32_t keyterm) {
+    uint32_t x = rowkey + keyterm;       // keyterm = (key >> 1) * 0x85EBCA6B
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15;
+    return x;
+}
+constexpr uint32_t kKeyMul = 0x85EBCA6Bu;
+
 __device__ __forceinline__ void block_map(int id, int nbh, int nblk, int& bh, int& blk) {
     // Workgroups b and b+8 share an XCD (round-robin dispatch): keep all blocks of one (b,h)
     // on one XCD so its K/V (or Q/dO) stream is served by that XCD's L2.  Speed only.
@@ -74,31 +104,24 @@ __device__ __forceinline__ void block_map(int id, int nbh, int nblk, int& bh, in
     }
 }
 
-template <bool DROP>
-__device__ __forceinline__ void drop_pair(const AttnArgs& a, uint64_t rowbase, int key, float& x0, float& x1) {
-    if constexpr (DROP) {
-        uint64_t idx = rowbase + (uint64_t)(key >> 1);
-        uint32_t bits = rng_pair(a.seed_lo, a.seed_hi, (uint32_t)idx, (uint32_t)(idx >> 32));
-        x0 = ((bits & 0xffffu) >= a.drop_thresh) ? x0 * a.keep_scale : 0.f;
-        x1 = ((bits >> 16) >= a.drop_thresh) ? x1 * a.keep_scale : 0.f;
-    }
-}
-template <bool DROP>
-__device__ __forceinline__ bool drop_keep(const AttnArgs& a, uint64_t rowbase, int key) {
-    if constexpr (DROP) {
-        uint64_t idx = rowbase + (uint64_t)(key >> 1);
-        uint32_t bits = rng_pair(a.seed_lo, a.seed_hi, (uint32_t)idx, (uint32_t)(idx >> 32));
-        return ((bits >> (16 * (key & 1))) & 0xffffu) >= a.drop_thresh;
-    } else {
-        return true;
+template <typename T, int NS, int DS, bool VEC>
+__device__ __forceinline__ void load_row_frags(const T* rowp, int h, bool valid, bf16x8 (&f)[NS][DS]) {
+#pragma unroll
+    for (int s = 0; s < DS; ++s) {
+        Chunk8<T> c = VEC ? load_chunk<T>(rowp + 16 * s + 8 * h, 8, true) : load_chunk<T>(rowp + 16 * s + 8 * h, 8, false);
+        if (!valid) c = zero_chunk<T>();
+        bf16x8 im[NS];
+        chunk_split<T>(c, im);
+#pragma unroll
+        for (int x = 0; x < NS; ++x) f[x][s] = im[x];
     }
 }
 
 // ---------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------
-template <typename T, int D, bool DROP>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
+template <typename T, int D, bool DROP, bool VEC>
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a) {
     constexpr int NS = NSplit<T>::value;
     constexpr int TILE = kKT * D;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -114,7 +137,6 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
     const T* kp = reinterpret_cast<const T*>(a.k) + b * a.k_sb + hh * a.k_sh;
     const T* vp = reinterpret_cast<const T*>(a.v) + b * a.v_sb + hh * a.v_sh;
     T* op = reinterpret_cast<T*>(a.o) + b * a.o_sb + hh * a.o_sh;
-    const bool vec = a.vec != 0;
 
     const int q0 = qb * kQB + wave * 32;
     const int qrow = q0 + r;
@@ -122,41 +144,35 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
     const int qrow_c = qvalid ? qrow : a.Nq - 1;
 
     bf16x8 qf[NS][D / 16];
-#pragma unroll
-    for (int s = 0; s < D / 16; ++s) {
-        Chunk8<T> c = load_chunk<T>(qp + (int64_t)qrow_c * a.q_sn + 16 * s + 8 * h, 8, vec);
-        bf16x8 im[NS];
-        chunk_split<T>(c, im);
-#pragma unroll
-        for (int x = 0; x < NS; ++x) qf[x][s] = im[x];
-    }
+    load_row_frags<T, NS, D / 16, VEC>(qp + (int64_t)qrow_c * a.q_sn, h, true, qf);
 
-    TileLoader<T, D> kl, vl;
+    TileLoader<T, D, VEC> kl, vl;
     auto Kt = [&](int buf) { return lds + (buf * 2 + 0) * NS * TILE; };
     auto Vt = [&](int buf) { return lds + (buf * 2 + 1) * NS * TILE; };
 
     const int nt = (a.Nk + kKT - 1) / kKT;
-    kl.issue(kp, a.k_sn, 0, a.Nk, vec, tid);
-    vl.issue(vp, a.v_sn, 0, a.Nk, vec, tid);
+    kl.issue(kp, a.k_sn, 0, a.Nk, tid);
+    vl.issue(vp, a.v_sn, 0, a.Nk, tid);
     kl.commit(Kt(0), tid);
     vl.commit(Vt(0), tid);
     __syncthreads();
 
     const float sl2 = a.scale * kLog2e;
-    float m = -INFINITY, l = 0.f;
+    float msc = -INFINITY;      // reference max in exp2 units (max * sl2); p = exp2(s * sl2 - msc) <= 2^kRescaleLog2
+    float l = 0.f;
     f32x16 o[D / 32];
 #pragma unroll
     for (int dt = 0; dt < D / 32; ++dt)
 #pragma unroll
         for (int i = 0; i < 16; ++i) o[dt][i] = 0.f;
 
-    const uint64_t rowbase = ((uint64_t)bh * a.Nq + qrow_c) * (uint64_t)((a.Nk + 1) >> 1);
+    const uint32_t rowkey = DROP ? drop_rowkey(a, bh, qrow_c) : 0u;
 
     for (int t = 0; t < nt; ++t) {
         const int buf = t & 1;
         if (t + 1 < nt) {
-            kl.issue(kp, a.k_sn, (t + 1) * kKT, a.Nk, vec, tid);
-            vl.issue(vp, a.v_sn, (t + 1) * kKT, a.Nk, vec, tid);
+            kl.issue(kp, a.k_sn, (t + 1) * kKT, a.Nk, tid);
+            vl.issue(vp, a.v_sn, (t + 1) * kKT, a.Nk, tid);
         }
         // S^T[key][q] = K Q^T
         f32x16 st[2];
@@ -188,35 +204,40 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
             for (int i = 0; i < 16; ++i) mloc = fmaxf(mloc, st[kt][i]);
-        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-        const float mnew = fmaxf(m, mloc);
-        const float alpha = __builtin_amdgcn_exp2f((m - mnew) * sl2);
-        const float msc = mnew * sl2;
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64)) * sl2;
+        // Deferred rescale: raise the reference max only when some row would overflow the 2^kRescaleLog2
+        // head-room (always on the first tile, where msc = -inf).  Wave-uniform branch; when taken, O, l
+        // and the reference are moved together, exactly once, before this tile's P is formed.
+        if (__any(mloc > msc + kRescaleLog2)) {
+            const float mnew = fmaxf(msc, mloc);
+            const float alpha = __builtin_amdgcn_exp2f(msc - mnew);
+            l *= alpha;
+#pragma unroll
+            for (int dt = 0; dt < D / 32; ++dt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) o[dt][i] *= alpha;
+            msc = mnew;
+        }
         float rs = 0.f;
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                float p = __builtin_amdgcn_exp2f(fmaf(st[kt][i], sl2, -msc));
+                const float p = __builtin_amdgcn_exp2f(fmaf(st[kt][i], sl2, -msc));
                 rs += p;
                 st[kt][i] = p;
             }
-        l = l * alpha + rs;
-        m = mnew;
+        l += rs;
         if constexpr (DROP) {
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
                 for (int i = 0; i < 16; i += 2) {
-                    float x0 = st[kt][i], x1 = st[kt][i + 1];
-                    drop_pair<DROP>(a, rowbase, kbase + 32 * kt + acc_row(i, h), x0, x1);
-                    st[kt][i] = x0; st[kt][i + 1] = x1;
+                    const uint32_t bits = drop_bits(rowkey, (uint32_t)((kbase + 32 * kt + acc_row(i, h)) >> 1) * kKeyMul);
+                    st[kt][i] = ((bits & 0xffffu) >= a.drop_thresh) ? st[kt][i] * a.keep_scale : 0.f;
+                    st[kt][i + 1] = ((bits >> 16) >= a.drop_thresh) ? st[kt][i + 1] * a.keep_scale : 0.f;
                 }
         }
-#pragma unroll
-        for (int dt = 0; dt < D / 32; ++dt)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) o[dt][i] *= alpha;
         // O^T[d][q] += V^T P^T
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
@@ -259,17 +280,17 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
                     bf16x4 w;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) w[j] = f2bf(o[dt][4 * g + j] * inv);
-                    if (vec) *reinterpret_cast<bf16x4*>(orow + d0) = w;
+                    if constexpr (VEC) *reinterpret_cast<bf16x4*>(orow + d0) = w;
                     else { for (int j = 0; j < 4; ++j) orow[d0 + j] = w[j]; }
                 } else {
                     f32x4 w;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) w[j] = o[dt][4 * g + j] * inv;
-                    if (vec) *reinterpret_cast<f32x4*>(orow + d0) = w;
+                    if constexpr (VEC) *reinterpret_cast<f32x4*>(orow + d0) = w;
                     else { for (int j = 0; j < 4; ++j) orow[d0 + j] = w[j]; }
                 }
             }
-        if (h == 0) a.lse[(int64_t)bh * a.Nq + qrow] = (m * sl2 + __builtin_amdgcn_logf(ltot)) * kLn2;
+        if (h == 0) a.lse[(int64_t)bh * a.Nq + qrow] = (msc + __builtin_amdgcn_logf(ltot)) * kLn2;
     }
 }
 
@@ -303,8 +324,8 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const AttnArgs a) {
 // ---------------------------------------------------------------------------------
 // backward: dQ
 // ---------------------------------------------------------------------------------
-template <typename T, int D, bool DROP>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs a) {
+template <typename T, int D, bool DROP, bool VEC>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
     constexpr int NS = NSplit<T>::value;
     constexpr int TILE = kKT * D;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -321,7 +342,6 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs a) {
     const T* vp = reinterpret_cast<const T*>(a.v) + b * a.v_sb + hh * a.v_sh;
     const T* dop = reinterpret_cast<const T*>(a.dout) + b * a.do_sb + hh * a.do_sh;
     T* dqp = reinterpret_cast<T*>(a.dq) + b * a.dq_sb + hh * a.dq_sh;
-    const bool vec = a.vec != 0;
 
     const int q0 = qb * kQB + wave * 32;
     const int qrow = q0 + r;
@@ -329,25 +349,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs a) {
     const int qrow_c = qvalid ? qrow : a.Nq - 1;
 
     bf16x8 qf[NS][D / 16], dof[NS][D / 16];
-#pragma unroll
-    for (int s = 0; s < D / 16; ++s) {
-        bf16x8 im[NS];
-        chunk_split<T>(load_chunk<T>(qp + (int64_t)qrow_c * a.q_sn + 16 * s + 8 * h, 8, vec), im);
-#pragma unroll
-        for (int x = 0; x < NS; ++x) qf[x][s] = im[x];
-        chunk_split<T>(load_chunk<T>(dop + (int64_t)qrow_c * a.do_sn + 16 * s + 8 * h, 8, vec), im);
-#pragma unroll
-        for (int x = 0; x < NS; ++x) dof[x][s] = im[x];
-    }
+    load_row_frags<T, NS, D / 16, VEC>(qp + (int64_t)qrow_c * a.q_sn, h, true, qf);
+    load_row_frags<T, NS, D / 16, VEC>(dop + (int64_t)qrow_c * a.do_sn, h, true, dof);
     const float lse2 = a.lse[(int64_t)bh * a.Nq + qrow_c] * kLog2e;
     const float delta = a.delta[(int64_t)bh * a.Nq + qrow_c];
 
-    TileLoader<T, D> kl, vl;
+    TileLoader<T, D, VEC> kl, vl;
     auto Kt = [&](int buf) { return lds + (buf * 2 + 0) * NS * TILE; };
     auto Vt = [&](int buf) { return lds + (buf * 2 + 1) * NS * TILE; };
     const int nt = (a.Nk + kKT - 1) / kKT;
-    kl.issue(kp, a.k_sn, 0, a.Nk, vec, tid);
-    vl.issue(vp, a.v_sn, 0, a.Nk, vec, tid);
+    kl.issue(kp, a.k_sn, 0, a.Nk, tid);
+    vl.issue(vp, a.v_sn, 0, a.Nk, tid);
     kl.commit(Kt(0), tid);
     vl.commit(Vt(0), tid);
     __syncthreads();
@@ -358,13 +370,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs a) {
     for (int dt = 0; dt < D / 32; ++dt)
 #pragma unroll
         for (int i = 0; i < 16; ++i) dq[dt][i] = 0.f;
-    const uint64_t rowbase = ((uint64_t)bh * a.Nq + qrow_c) * (uint64_t)((a.Nk + 1) >> 1);
+    const uint32_t rowkey = DROP ? drop_rowkey(a, bh, qrow_c) : 0u;
 
     for (int t = 0; t < nt; ++t) {
         const int buf = t & 1;
         if (t + 1 < nt) {
-            kl.issue(kp, a.k_sn, (t + 1) * kKT, a.Nk, vec, tid);
-            vl.issue(vp, a.v_sn, (t + 1) * kKT, a.Nk, vec, tid);
+            kl.issue(kp, a.k_sn, (t + 1) * kKT, a.Nk, tid);
+            vl.issue(vp, a.v_sn, (t + 1) * kKT, a.Nk, tid);
         }
         f32x16 st[2], dpt[2];
 #pragma unroll
@@ -387,6 +399,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs a) {
             }
         }
         const int kbase = t * kKT;
+        const bool tail = kbase + kKT > a.Nk;
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -394,10 +407,16 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs a) {
                 const int key = kbase + 32 * kt + acc_row(i, h);
                 float p0 = __builtin_amdgcn_exp2f(fmaf(st[kt][i], sl2, -lse2));
                 float p1 = __builtin_amdgcn_exp2f(fmaf(st[kt][i + 1], sl2, -lse2));
-                if (key >= a.Nk) p0 = 0.f;
-                if (key + 1 >= a.Nk) p1 = 0.f;
+                if (tail) {
+                    if (key >= a.Nk) p0 = 0.f;
+                    if (key + 1 >= a.Nk) p1 = 0.f;
+                }
                 float d0 = dpt[kt][i], d1 = dpt[kt][i + 1];
-                drop_pair<DROP>(a, rowbase, key, d0, d1);
+                if constexpr (DROP) {
+                    const uint32_t bits = drop_bits(rowkey, (uint32_t)(key >> 1) * kKeyMul);
+                    d0 = ((bits & 0xffffu) >= a.drop_thresh) ? d0 * a.keep_scale : 0.f;
+                    d1 = ((bits >> 16) >= a.drop_thresh) ? d1 * a.keep_scale : 0.f;
+                }
                 st[kt][i] = p0 * (d0 - delta);
                 st[kt][i + 1] = p1 * (d1 - delta);
             }
@@ -442,13 +461,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs a) {
 // ---------------------------------------------------------------------------------
 // backward: dK, dV
 // ---------------------------------------------------------------------------------
-template <typename T, int D, bool DROP>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs a) {
+template <typename T, int D, bool DROP, bool VEC>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a) {
     constexpr int NS = NSplit<T>::value;
     constexpr int TILE = kKT * D;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16* lds = reinterpret_cast<bf16*>(smem);                       // [buf][Q|dO][NS][TILE]
-    float* stat = reinterpret_cast<float*>(lds + 4 * NS * TILE);     // [buf][lse2|delta][kKT]
+    float* stat = reinterpret_cast<float*>(lds + 4 * NS * TILE);     // [buf][lse2|delta|rowkey][kKT]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
 
@@ -462,41 +481,40 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs a) {
     const T* dop = reinterpret_cast<const T*>(a.dout) + b * a.do_sb + hh * a.do_sh;
     T* dkp = reinterpret_cast<T*>(a.dk) + b * a.dk_sb + hh * a.dk_sh;
     T* dvp = reinterpret_cast<T*>(a.dv) + b * a.dv_sb + hh * a.dv_sh;
-    const bool vec = a.vec != 0;
 
     const int k0 = kb * kQB + wave * 32;
     const int krow = k0 + r;
     const bool kvalid = krow < a.Nk;
+    const int krow_c = kvalid ? krow : a.Nk - 1;
 
     bf16x8 kf[NS][D / 16], vf[NS][D / 16];
-#pragma unroll
-    for (int s = 0; s < D / 16; ++s) {
-        bf16x8 im[NS];
-        chunk_split<T>(load_chunk<T>(kp + (int64_t)krow * a.k_sn + 16 * s + 8 * h, kvalid ? 8 : 0, vec), im);
-#pragma unroll
-        for (int x = 0; x < NS; ++x) kf[x][s] = im[x];
-        chunk_split<T>(load_chunk<T>(vp + (int64_t)krow * a.v_sn + 16 * s + 8 * h, kvalid ? 8 : 0, vec), im);
-#pragma unroll
-        for (int x = 0; x < NS; ++x) vf[x][s] = im[x];
-    }
+    load_row_frags<T, NS, D / 16, VEC>(kp + (int64_t)krow_c * a.k_sn, h, kvalid, kf);
+    load_row_frags<T, NS, D / 16, VEC>(vp + (int64_t)krow_c * a.v_sn, h, kvalid, vf);
 
-    TileLoader<T, D> ql, dl;
+    TileLoader<T, D, VEC> ql, dl;
     auto Qt = [&](int buf) { return lds + (buf * 2 + 0) * NS * TILE; };
     auto Dt = [&](int buf) { return lds + (buf * 2 + 1) * NS * TILE; };
     const int nt = (a.Nq + kKT - 1) / kKT;
     float st_l = 0.f, st_d = 0.f;
+    uint32_t st_k = 0u;
     auto issue_stat = [&](int t) {
         if (tid < kKT) {
             int q = t * kKT + tid;
-            st_l = q < a.Nq ? a.lse[(int64_t)bh * a.Nq + q] * kLog2e : INFINITY;
-            st_d = q < a.Nq ? a.delta[(int64_t)bh * a.Nq + q] : 0.f;
+            const bool ok = q < a.Nq;
+            st_l = ok ? a.lse[(int64_t)bh * a.Nq + q] * kLog2e : INFINITY;
+            st_d = ok ? a.delta[(int64_t)bh * a.Nq + q] : 0.f;
+            if constexpr (DROP) st_k = drop_rowkey(a, bh, ok ? q : a.Nq - 1);
         }
     };
     auto commit_stat = [&](int buf) {
-        if (tid < kKT) { stat[(buf * 2 + 0) * kKT + tid] = st_l; stat[(buf * 2 + 1) * kKT + tid] = st_d; }
+        if (tid < kKT) {
+            stat[(buf * 3 + 0) * kKT + tid] = st_l;
+            stat[(buf * 3 + 1) * kKT + tid] = st_d;
+            if constexpr (DROP) reinterpret_cast<uint32_t*>(stat)[(buf * 3 + 2) * kKT + tid] = st_k;
+        }
     };
-    ql.issue(qp, a.q_sn, 0, a.Nq, vec, tid);
-    dl.issue(dop, a.do_sn, 0, a.Nq, vec, tid);
+    ql.issue(qp, a.q_sn, 0, a.Nq, tid);
+    dl.issue(dop, a.do_sn, 0, a.Nq, tid);
     issue_stat(0);
     ql.commit(Qt(0), tid);
     dl.commit(Dt(0), tid);
@@ -509,13 +527,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs a) {
     for (int dt = 0; dt < D / 32; ++dt)
 #pragma unroll
         for (int i = 0; i < 16; ++i) { dk[dt][i] = 0.f; dv[dt][i] = 0.f; }
-    const uint64_t halfk = (uint64_t)((a.Nk + 1) >> 1);
+    const uint32_t keyterm = (uint32_t)((kvalid ? krow : 0) >> 1) * kKeyMul;
+    const int lot_shift = 16 * (krow & 1);
 
     for (int t = 0; t < nt; ++t) {
         const int buf = t & 1;
         if (t + 1 < nt) {
-            ql.issue(qp, a.q_sn, (t + 1) * kKT, a.Nq, vec, tid);
-            dl.issue(dop, a.do_sn, (t + 1) * kKT, a.Nq, vec, tid);
+            ql.issue(qp, a.q_sn, (t + 1) * kKT, a.Nq, tid);
+            dl.issue(dop, a.do_sn, (t + 1) * kKT, a.Nq, tid);
             issue_stat(t + 1);
         }
 #pragma unroll
@@ -541,19 +560,20 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs a) {
             float pd[16], ds[16];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const f32x4 l4 = *reinterpret_cast<const f32x4*>(stat + (buf * 2 + 0) * kKT + 32 * qt + 8 * g + 4 * h);
-                const f32x4 d4 = *reinterpret_cast<const f32x4*>(stat + (buf * 2 + 1) * kKT + 32 * qt + 8 * g + 4 * h);
+                const int ro = 32 * qt + 8 * g + 4 * h;
+                const f32x4 l4 = *reinterpret_cast<const f32x4*>(stat + (buf * 3 + 0) * kKT + ro);
+                const f32x4 d4 = *reinterpret_cast<const f32x4*>(stat + (buf * 3 + 1) * kKT + ro);
+                typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+                u32x4 k4 = {0u, 0u, 0u, 0u};
+                if constexpr (DROP) k4 = *reinterpret_cast<const u32x4*>(reinterpret_cast<const uint32_t*>(stat) + (buf * 3 + 2) * kKT + ro);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int i = 4 * g + j;
-                    float p = __builtin_amdgcn_exp2f(fmaf(s[i], sl2, -l4[j]));
+                    const float p = __builtin_amdgcn_exp2f(fmaf(s[i], sl2, -l4[j]));
                     float dpv = dp[i];
                     float pdv = p;
                     if constexpr (DROP) {
-                        const int q = t * kKT + 32 * qt + 8 * g + 4 * h + j;
-                        const int qc = q < a.Nq ? q : a.Nq - 1;
-                        const uint64_t rowbase = ((uint64_t)bh * a.Nq + qc) * halfk;
-                        const bool keep = drop_keep<DROP>(a, rowbase, kvalid ? krow : 0);
+                        const bool keep = ((drop_bits(k4[j], keyterm) >> lot_shift) & 0xffffu) >= a.drop_thresh;
                         pdv = keep ? p * a.keep_scale : 0.f;
                         dpv = keep ? dpv * a.keep_scale : 0.f;
                     }
@@ -608,7 +628,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs a) {
 template <typename T, int D>
 size_t fwd_lds_bytes() { return (size_t)2 * 2 * NSplit<T>::value * kKT * D * sizeof(bf16); }
 template <typename T, int D>
-size_t dkv_lds_bytes() { return fwd_lds_bytes<T, D>() + 2 * 2 * kKT * sizeof(float); }
+size_t dkv_lds_bytes() { return fwd_lds_bytes<T, D>() + 2 * 3 * kKT * sizeof(float); }
 
 template <typename K>
 hipError_t set_lds(K kernel, size_t bytes) {
@@ -617,18 +637,18 @@ hipError_t set_lds(K kernel, size_t bytes) {
     return hipSuccess;
 }
 
-template <typename T, int D, bool DROP>
+template <typename T, int D, bool DROP, bool VEC>
 hipError_t launch_fwd(const AttnArgs& a, hipStream_t st) {
     const int nqb = (a.Nq + kQB - 1) / kQB;
     const size_t lds = fwd_lds_bytes<T, D>();
-    auto k = attn_fwd_kernel<T, D, DROP>;
+    auto k = attn_fwd_kernel<T, D, DROP, VEC>;
     hipError_t e = set_lds(k, lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k, dim3(nqb * a.B * a.H), dim3(256), lds, st, a);
     return hipGetLastError();
 }
 
-template <typename T, int D, bool DROP>
+template <typename T, int D, bool DROP, bool VEC>
 hipError_t launch_bwd(const AttnArgs& a, hipStream_t st) {
     {
         const int64_t nthreads = (int64_t)a.B * a.H * a.Nq * (D / 8);
@@ -639,7 +659,7 @@ hipError_t launch_bwd(const AttnArgs& a, hipStream_t st) {
     {
         const int nkb = (a.Nk + kQB - 1) / kQB;
         const size_t lds = dkv_lds_bytes<T, D>();
-        auto k = attn_bwd_dkv_kernel<T, D, DROP>;
+        auto k = attn_bwd_dkv_kernel<T, D, DROP, VEC>;
         hipError_t e = set_lds(k, lds);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(k, dim3(nkb * a.B * a.H), dim3(256), lds, st, a);
@@ -649,7 +669,7 @@ hipError_t launch_bwd(const AttnArgs& a, hipStream_t st) {
     {
         const int nqb = (a.Nq + kQB - 1) / kQB;
         const size_t lds = fwd_lds_bytes<T, D>();
-        auto k = attn_bwd_dq_kernel<T, D, DROP>;
+        auto k = attn_bwd_dq_kernel<T, D, DROP, VEC>;
         hipError_t e = set_lds(k, lds);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(k, dim3(nqb * a.B * a.H), dim3(256), lds, st, a);
@@ -657,17 +677,17 @@ hipError_t launch_bwd(const AttnArgs& a, hipStream_t st) {
     }
 }
 
+template <typename T, int D, bool DROP>
+hipError_t dispatch_vec(const AttnArgs& a, bool bwd, hipStream_t st) {
+    if (a.vec) return bwd ? launch_bwd<T, D, DROP, true>(a, st) : launch_fwd<T, D, DROP, true>(a, st);
+    return bwd ? launch_bwd<T, D, DROP, false>(a, st) : launch_fwd<T, D, DROP, false>(a, st);
+}
+
 template <typename T>
 hipError_t dispatch(const AttnArgs& a, bool bwd, hipStream_t st) {
     const bool drop = a.drop_thresh != 0;
-    if (a.D == 64) {
-        if (drop) return bwd ? launch_bwd<T, 64, true>(a, st) : launch_fwd<T, 64, true>(a, st);
-        return bwd ? launch_bwd<T, 64, false>(a, st) : launch_fwd<T, 64, false>(a, st);
-    }
-    if (a.D == 32) {
-        if (drop) return bwd ? launch_bwd<T, 32, true>(a, st) : launch_fwd<T, 32, true>(a, st);
-        return bwd ? launch_bwd<T, 32, false>(a, st) : launch_fwd<T, 32, false>(a, st);
-    }
+    if (a.D == 64) return drop ? dispatch_vec<T, 64, true>(a, bwd, st) : dispatch_vec<T, 64, false>(a, bwd, st);
+    if (a.D == 32) return drop ? dispatch_vec<T, 32, true>(a, bwd, st) : dispatch_vec<T, 32, false>(a, bwd, st);
     return hipErrorInvalidValue;
 }
 

@@ -139,6 +139,9 @@ int hvc_gemm(const void* A, const void* B, void* C, int M, int N, int K,
     g.vec_a = aligned16(A) && (lda % 8 == 0);
     g.vec_b = aligned16(B) && (ldb % 8 == 0);
     g.workspace = workspace; g.workspace_floats = workspace ? workspace_floats : 0;
+    g.vec_epi = (N % 8 == 0) && aligned16(C) && (ldc % 8 == 0) && (!aux || aligned16(aux)) &&
+                (!zsave || (aligned16(zsave) && ldz % 8 == 0)) && (!residual || (aligned16(residual) && ldr % 8 == 0)) &&
+                (!workspace || aligned16(workspace));
     return hip_result(hvc::gemm_launch(g, (hipStream_t)stream), "gemm");
 }
 

@@ -28,6 +28,36 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
     return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
 }
 
+// n (<= 8) consecutive elements <-> 8 floats; vec: one 16-byte (bf16) / two 16-byte (fp32) accesses.
+template <typename T>
+__device__ __forceinline__ void load_n(const T* p, float (&v)[8], int n, bool vec) {
+    if (vec) {
+        Chunk8<T> c = load_chunk<T>(p, 8, true);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = chunk_get<T>(c, e);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = e < n ? to_f<T>(p[e]) : 0.f;
+    }
+}
+template <typename T>
+__device__ __forceinline__ void store_n(T* p, const float (&v)[8], int n, bool vec) {
+    if (vec) {
+        if constexpr (sizeof(T) == 2) {
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = f2bf(v[e]);
+            *reinterpret_cast<bf16x8*>(p) = o;
+        } else {
+            *reinterpret_cast<f32x4*>(p) = f32x4{v[0], v[1], v[2], v[3]};
+            *reinterpret_cast<f32x4*>(p + 4) = f32x4{v[4], v[5], v[6], v[7]};
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) if (e < n) p[e] = from_f<T>(v[e]);
+    }
+}
+
 // Operand tile loader.  KM = false: LDS image [128 rows][BK] (row = i, k contiguous);
 //                       KM = true : LDS image [BK rows][128] (row = k, i contiguous).
 template <typename T, int BK, bool KM>
@@ -76,7 +106,7 @@ struct OperandTile {
 };
 
 template <typename TI, typename TO, bool AKM, bool BKM>
-__global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
     constexpr int NS = NSplit<TI>::value;
     constexpr int BK = sizeof(TI) == 2 ? 64 : 32;
     using TA = OperandTile<TI, BK, AKM>;
@@ -84,6 +114,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16* lds = reinterpret_cast<bf16*>(smem);
     constexpr int A_SZ = NS * TA::IMG, B_SZ = NS * TB::IMG;
+    static_assert(2 * (A_SZ + B_SZ) * sizeof(bf16) >= kBM * kBN * sizeof(float), "epilogue staging reuses the operand buffers");
     auto At = [&](int buf) { return lds + buf * (A_SZ + B_SZ); };
     auto Bt = [&](int buf) { return lds + buf * (A_SZ + B_SZ) + A_SZ; };
 
@@ -159,57 +190,91 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
         __syncthreads();
     }
 
+    // ---- epilogue: stage the 128 x 128 fp32 tile through LDS (the operand buffers are free now) so that
+    // every global access of the epilogue is a 16/32-byte row segment instead of a 2/4-byte column element.
+    float* stage = reinterpret_cast<float*>(smem);          // [128][128] fp32 = 64 KiB = the operand double buffer
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int x = 0; x < 16; ++x)
+                stage[(64 * wm + 32 * mi + acc_row(x, h)) * kBN + 64 * wn + 32 * ni + r] = acc[mi][ni][x];
+    __syncthreads();
+
+    const int ch = tid & 15;                 // 8-column chunk of the tile row handled by this thread
+    const int j = j0 + ch * 8;
+    if (j >= g.N) return;
+    const int nj = min(8, g.N - j);
+    const bool vec = g.vec_epi != 0 && nj == 8;
+
     if (g.splitk > 1) {   // raw fp32 partial tile -> slab `split` of the workspace; reduced by splitk_reduce_kernel
         float* ws = g.workspace + (size_t)split * g.M * g.N;
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-            const int j = j0 + 64 * wn + 32 * ni + r;
-            if (j >= g.N) continue;
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                for (int x = 0; x < 16; ++x) {
-                    const int i = i0 + 64 * wm + 32 * mi + acc_row(x, h);
-                    if (i < g.M) ws[(size_t)i * g.N + j] = acc[mi][ni][x];
-                }
+        for (int row = tid >> 4; row < kBM; row += 16) {
+            const int i = i0 + row;
+            if (i >= g.M) break;
+            const float* sp = stage + row * kBN + ch * 8;
+            float* dst = ws + (size_t)i * g.N + j;
+            if (vec) {
+                *reinterpret_cast<f32x4*>(dst) = *reinterpret_cast<const f32x4*>(sp);
+                *reinterpret_cast<f32x4*>(dst + 4) = *reinterpret_cast<const f32x4*>(sp + 4);
+            } else {
+                for (int e = 0; e < nj; ++e) dst[e] = sp[e];
+            }
         }
         return;
     }
-    // epilogue: rows in registers, columns on lanes -> each store instruction writes 32
-    // consecutive columns of one row.
+
     TO* Cp = reinterpret_cast<TO*>(g.C);
     TO* auxp = reinterpret_cast<TO*>(g.aux);
     TI* zp = reinterpret_cast<TI*>(g.zsave);
+    float bj[8];
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-        const int j = j0 + 64 * wn + 32 * ni + r;
-        if (j >= g.N) continue;
-        const float bj = g.bias ? g.bias[j] : 0.f;
+    for (int e = 0; e < 8; ++e) bj[e] = (g.bias && e < nj) ? g.bias[j + e] : 0.f;
+
+    for (int row = tid >> 4; row < kBM; row += 16) {
+        const int i = i0 + row;
+        if (i >= g.M) break;
+        float v[8];
+        {
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(stage + row * kBN + ch * 8);
+            const f32x4 a1 = *reinterpret_cast<const f32x4*>(stage + row * kBN + ch * 8 + 4);
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
+            for (int e = 0; e < 4; ++e) { v[e] = a0[e] * g.alpha + bj[e]; v[4 + e] = a1[e] * g.alpha + bj[4 + e]; }
+        }
+        const int64_t co = (int64_t)i * g.ldc + j;
+        if (g.act == kActGelu) {
+            if (auxp) store_n<TO>(auxp + co, v, nj, vec);
 #pragma unroll
-            for (int x = 0; x < 16; ++x) {
-                const int i = i0 + 64 * wm + 32 * mi + acc_row(x, h);
-                if (i >= g.M) continue;
-                float v = acc[mi][ni][x] * g.alpha + bj;
-                if (g.act == kActGelu) {
-                    if (auxp) auxp[(int64_t)i * g.ldc + j] = from_f<TO>(v);
-                    v = gelu_f(v);
-                } else if (g.act == kActGeluGrad) {
-                    v *= gelu_grad_f(to_f<TO>(auxp[(int64_t)i * g.ldc + j]));
-                }
-                if (g.drop_thresh) {
-                    const uint64_t e = (uint64_t)i * (uint64_t)g.N + (uint64_t)j;
-                    const uint32_t bits = rng_pair(g.seed_lo, g.seed_hi, (uint32_t)(e >> 1), (uint32_t)(e >> 33));
-                    const bool keep = ((bits >> (16 * (e & 1))) & 0xffffu) >= g.drop_thresh;
-                    v = keep ? v * g.keep_scale : 0.f;
-                }
-                if (zp) zp[(int64_t)i * g.ldz + j] = from_f<TI>(v);
-                if (g.gate) v *= g.gate[(int64_t)(i / g.rows_per_batch) * g.N + j];
-                if (g.residual) v += g.residual[(int64_t)(g.residual_rows > 0 ? i % g.residual_rows : i) * g.ldr + j];
-                Cp[(int64_t)i * g.ldc + j] = from_f<TO>(v);
+            for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+        } else if (g.act == kActGeluGrad) {
+            float pre[8];
+            load_n<TO>(auxp + co, pre, nj, vec);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] *= gelu_grad_f(pre[e]);
+        }
+        if (g.drop_thresh) {
+            const uint64_t e0 = (uint64_t)i * (uint64_t)g.N + (uint64_t)j;     // even when vec (N, j multiples of 8)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const uint64_t el = e0 + e;
+                const uint32_t bits = rng_pair(g.seed_lo, g.seed_hi, (uint32_t)(el >> 1), (uint32_t)(el >> 33));
+                v[e] = (((bits >> (16 * (el & 1))) & 0xffffu) >= g.drop_thresh) ? v[e] * g.keep_scale : 0.f;
             }
         }
+        if (zp) store_n<TI>(zp + (int64_t)i * g.ldz + j, v, nj, vec);
+        if (g.gate) {
+            const float* gp = g.gate + (int64_t)(i / g.rows_per_batch) * g.N + j;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) if (e < nj) v[e] *= gp[e];
+        }
+        if (g.residual) {
+            float rv[8];
+            load_n<float>(g.residual + (int64_t)(g.residual_rows > 0 ? i % g.residual_rows : i) * g.ldr + j, rv, nj, vec);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += rv[e];
+        }
+        store_n<TO>(Cp + co, v, nj, vec);
     }
 }
 

@@ -200,6 +200,20 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// Second stage of the deterministic two-stage column reductions: sum partial[r * stride + c] over
+// r in [0, nrows) for column c = 32 * blockIdx.x + (tid & 31).  256 threads = 32 columns x 8 row
+// groups; fixed summation order.  Returns the sum in the threads with (tid >> 5) == 0.
+__device__ __forceinline__ float block_colsum32(const float* __restrict__ partial, int nrows, int64_t stride, int c, bool valid,
+                                                float (*red)[32]) {
+    const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    float s = 0.f;
+    if (valid)
+        for (int r = rg; r < nrows; r += 8) s += partial[(int64_t)r * stride + c];
+    red[rg][cl] = s;
+    __syncthreads();
+    return ((red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl])) + ((red[4][cl] + red[5][cl]) + (red[6][cl] + red[7][cl]));
+}
+
 template <typename T> __device__ __forceinline__ float to_f(T x);
 template <> __device__ __forceinline__ float to_f<float>(float x) { return x; }
 template <> __device__ __forceinline__ float to_f<bf16>(bf16 x) { return bf2f(x); }

@@ -55,6 +55,7 @@ struct GemmArgs {
     float keep_scale;
     int in_bf16, out_bf16;
     int vec_a, vec_b;
+    int vec_epi;             // every epilogue operand allows 16-byte row-segment access
     float* workspace;        // optional split-K scratch (fp32), workspace_floats long
     int64_t workspace_floats;
     int splitk;              // filled in by the launcher
