@@ -23,6 +23,8 @@
 //            64-query tiles (Q, dO in LDS, read row-wise for S / dP and transposed for dV / dK).
 // The split backward recomputes S twice (7 products instead of 5) in exchange for having no
 // cross-workgroup reduction: dQ, dK, dV are bitwise reproducible.
+#include <type_traits>
+
 #include "hvc_common.hip.h"
 #include "hvc_kernels.h"
 
@@ -78,18 +80,30 @@ struct TileLoader {
 };
 
 // ---- attention-probability dropout ------------------------------------------------------------------
-// keep(b,h,q,k) = lot16(hash(rowkey(b,h,q) + (k >> 1) * C), k & 1) >= thresh.  rowkey is one 32-bit word
-// per query row (computed once per lane, or once per LDS tile row in the dKV kernel), so the
-// per-element cost is one multiply-xorshift round shared by two keys plus a compare and a select.
+// keep(b,h,q,k) = lot16(k & 3 of hash4(rowkey(b,h,q) + (k >> 2) * C)) >= thresh.  rowkey is one 32-bit word
+// per query row (computed once per lane, or once per LDS tile row in the dKV kernel); one
+// multiply-xorshift round with two multipliers yields four 16-bit lots, i.e. four consecutive keys
+// share the hash and each element costs a compare and a select.  The 1/(1-p) factor is applied once
+// to the accumulators in the epilogues, not per element.
 __device__ __forceinline__ uint32_t drop_rowkey(const AttnArgs& a, int bh, int q) {
     return mix32(((uint32_t)(bh * a.Nq + q) * 0x9E3779B1u) ^ a.seed_lo) ^ a.seed_hi;
 }
-__device__ __forceinline__ uint32_t drop_bits(uint32_t rowkey, uint32_t keyterm) {
-    uint32_t x = rowkey + keyterm;       // keyterm = (key >> 1) * 0x85EBCA6B
-    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15;
-    return x;
+constexpr uint32_t kKeyMul = 0x85EBCA6Bu, kLotMulA = 0x7feb352dU, kLotMulB = 0x846ca68bU;
+__device__ __forceinline__ uint32_t drop_mix(uint32_t rowkey, uint32_t keyterm) {   // keyterm = (key >> 2) * kKeyMul
+    uint32_t x = rowkey + keyterm;
+    return x ^ (x >> 16);
 }
-constexpr uint32_t kKeyMul = 0x85EBCA6Bu;
+__device__ __forceinline__ uint32_t drop_lots(uint32_t mixed, uint32_t mul) {        // two 16-bit lots
+    uint32_t y = mixed * mul;
+    return y ^ (y >> 15);
+}
+// keep flags of the four consecutive keys 4*(key>>2) .. +3
+__device__ __forceinline__ void drop_keep4(uint32_t rowkey, int key, uint32_t thresh, bool (&keep)[4]) {
+    const uint32_t m = drop_mix(rowkey, (uint32_t)(key >> 2) * kKeyMul);
+    const uint32_t a = drop_lots(m, kLotMulA), b = drop_lots(m, kLotMulB);
+    keep[0] = (a & 0xffffu) >= thresh; keep[1] = (a >> 16) >= thresh;
+    keep[2] = (b & 0xffffu) >= thresh; keep[3] = (b >> 16) >= thresh;
+}
 
 __device__ __forceinline__ void block_map(int id, int nbh, int nblk, int& bh, int& blk) {
     // Workgroups b and b+8 share an XCD (round-robin dispatch): keep all blocks of one (b,h)
@@ -168,7 +182,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a) {
 
     const uint32_t rowkey = DROP ? drop_rowkey(a, bh, qrow_c) : 0u;
 
-    for (int t = 0; t < nt; ++t) {
+    // One 64-key tile.  MASK is only instantiated for a ragged last tile, so the full tiles carry no
+    // per-element bounds selects.
+    auto tile = [&](auto mask_tag, int t) {
+        constexpr bool MASK = decltype(mask_tag)::value;
         const int buf = t & 1;
         if (t + 1 < nt) {
             kl.issue(kp, a.k_sn, (t + 1) * kKT, a.Nk, tid);
@@ -192,7 +209,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a) {
             }
         }
         const int kbase = t * kKT;
-        if (kbase + kKT > a.Nk) {
+        if constexpr (MASK) {
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -232,10 +249,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a) {
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-                for (int i = 0; i < 16; i += 2) {
-                    const uint32_t bits = drop_bits(rowkey, (uint32_t)((kbase + 32 * kt + acc_row(i, h)) >> 1) * kKeyMul);
-                    st[kt][i] = ((bits & 0xffffu) >= a.drop_thresh) ? st[kt][i] * a.keep_scale : 0.f;
-                    st[kt][i + 1] = ((bits >> 16) >= a.drop_thresh) ? st[kt][i + 1] * a.keep_scale : 0.f;
+                for (int i = 0; i < 16; i += 4) {
+                    bool keep[4];
+                    drop_keep4(rowkey, kbase + 32 * kt + acc_row(i, h), a.drop_thresh, keep);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) st[kt][i + j] = keep[j] ? st[kt][i + j] : 0.f;
                 }
         }
         // O^T[d][q] += V^T P^T
@@ -265,10 +283,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a) {
             vl.commit(Vt(buf ^ 1), tid);
         }
         __syncthreads();
-    }
+    };
+    const bool ragged = (a.Nk % kKT) != 0;
+    const int nfull = ragged ? nt - 1 : nt;
+    for (int t = 0; t < nfull; ++t) tile(std::false_type{}, t);
+    if (ragged) tile(std::true_type{}, nt - 1);
 
     const float ltot = l + __shfl_xor(l, 32, 64);
-    const float inv = 1.f / ltot;
+    const float inv = (DROP ? a.keep_scale : 1.f) / ltot;
     if (qvalid) {
         T* orow = op + (int64_t)qrow * a.o_sn;
 #pragma unroll
@@ -352,7 +374,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
     load_row_frags<T, NS, D / 16, VEC>(qp + (int64_t)qrow_c * a.q_sn, h, true, qf);
     load_row_frags<T, NS, D / 16, VEC>(dop + (int64_t)qrow_c * a.do_sn, h, true, dof);
     const float lse2 = a.lse[(int64_t)bh * a.Nq + qrow_c] * kLog2e;
-    const float delta = a.delta[(int64_t)bh * a.Nq + qrow_c];
+    const float delta = a.delta[(int64_t)bh * a.Nq + qrow_c] * (DROP ? 1.f / a.keep_scale : 1.f);
 
     TileLoader<T, D, VEC> kl, vl;
     auto Kt = [&](int buf) { return lds + (buf * 2 + 0) * NS * TILE; };
@@ -372,7 +394,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
         for (int i = 0; i < 16; ++i) dq[dt][i] = 0.f;
     const uint32_t rowkey = DROP ? drop_rowkey(a, bh, qrow_c) : 0u;
 
-    for (int t = 0; t < nt; ++t) {
+    auto tile = [&](auto mask_tag, int t) {
+        constexpr bool MASK = decltype(mask_tag)::value;
         const int buf = t & 1;
         if (t + 1 < nt) {
             kl.issue(kp, a.k_sn, (t + 1) * kKT, a.Nk, tid);
@@ -399,26 +422,21 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
             }
         }
         const int kbase = t * kKT;
-        const bool tail = kbase + kKT > a.Nk;
+        // dS / keep_scale = p * (keep * dP - delta / keep_scale); keep_scale rejoins in the epilogue
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-            for (int i = 0; i < 16; i += 2) {
+            for (int i = 0; i < 16; i += 4) {
                 const int key = kbase + 32 * kt + acc_row(i, h);
-                float p0 = __builtin_amdgcn_exp2f(fmaf(st[kt][i], sl2, -lse2));
-                float p1 = __builtin_amdgcn_exp2f(fmaf(st[kt][i + 1], sl2, -lse2));
-                if (tail) {
-                    if (key >= a.Nk) p0 = 0.f;
-                    if (key + 1 >= a.Nk) p1 = 0.f;
+                bool keep[4] = {true, true, true, true};
+                if constexpr (DROP) drop_keep4(rowkey, key, a.drop_thresh, keep);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float p = __builtin_amdgcn_exp2f(fmaf(st[kt][i + j], sl2, -lse2));
+                    if constexpr (MASK) { if (key + j >= a.Nk) p = 0.f; }
+                    const float d = keep[j] ? dpt[kt][i + j] : 0.f;
+                    st[kt][i + j] = p * (d - delta);
                 }
-                float d0 = dpt[kt][i], d1 = dpt[kt][i + 1];
-                if constexpr (DROP) {
-                    const uint32_t bits = drop_bits(rowkey, (uint32_t)(key >> 1) * kKeyMul);
-                    d0 = ((bits & 0xffffu) >= a.drop_thresh) ? d0 * a.keep_scale : 0.f;
-                    d1 = ((bits >> 16) >= a.drop_thresh) ? d1 * a.keep_scale : 0.f;
-                }
-                st[kt][i] = p0 * (d0 - delta);
-                st[kt][i + 1] = p1 * (d1 - delta);
             }
         // dQ[q][d] += dS K  (dS^T accumulators as the A operand, K through the transposed read)
 #pragma unroll
@@ -447,14 +465,19 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
             vl.commit(Vt(buf ^ 1), tid);
         }
         __syncthreads();
-    }
+    };
+    const bool ragged = (a.Nk % kKT) != 0;
+    const int nfull = ragged ? nt - 1 : nt;
+    for (int t = 0; t < nfull; ++t) tile(std::false_type{}, t);
+    if (ragged) tile(std::true_type{}, nt - 1);
+    const float oscale = a.scale * (DROP ? a.keep_scale : 1.f);
     // dq tile: rows = q (registers), col = d (lane)
 #pragma unroll
     for (int dt = 0; dt < D / 32; ++dt)
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int qq = q0 + acc_row(i, h);
-            if (qq < a.Nq) dqp[(int64_t)qq * a.dq_sn + 32 * dt + r] = from_f<T>(dq[dt][i] * a.scale);
+            if (qq < a.Nq) dqp[(int64_t)qq * a.dq_sn + 32 * dt + r] = from_f<T>(dq[dt][i] * oscale);
         }
 }
 
@@ -502,7 +525,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a) 
             int q = t * kKT + tid;
             const bool ok = q < a.Nq;
             st_l = ok ? a.lse[(int64_t)bh * a.Nq + q] * kLog2e : INFINITY;
-            st_d = ok ? a.delta[(int64_t)bh * a.Nq + q] : 0.f;
+            st_d = ok ? a.delta[(int64_t)bh * a.Nq + q] * (DROP ? 1.f / a.keep_scale : 1.f) : 0.f;
             if constexpr (DROP) st_k = drop_rowkey(a, bh, ok ? q : a.Nq - 1);
         }
     };
@@ -527,7 +550,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a) 
     for (int dt = 0; dt < D / 32; ++dt)
 #pragma unroll
         for (int i = 0; i < 16; ++i) { dk[dt][i] = 0.f; dv[dt][i] = 0.f; }
-    const uint32_t keyterm = (uint32_t)((kvalid ? krow : 0) >> 1) * kKeyMul;
+    const uint32_t keyterm = (uint32_t)((kvalid ? krow : 0) >> 2) * kKeyMul;
+    const uint32_t lotmul = (krow & 2) ? kLotMulB : kLotMulA;
     const int lot_shift = 16 * (krow & 1);
 
     for (int t = 0; t < nt; ++t) {
@@ -572,10 +596,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a) 
                     const float p = __builtin_amdgcn_exp2f(fmaf(s[i], sl2, -l4[j]));
                     float dpv = dp[i];
                     float pdv = p;
-                    if constexpr (DROP) {
-                        const bool keep = ((drop_bits(k4[j], keyterm) >> lot_shift) & 0xffffu) >= a.drop_thresh;
-                        pdv = keep ? p * a.keep_scale : 0.f;
-                        dpv = keep ? dpv * a.keep_scale : 0.f;
+                    if constexpr (DROP) {   // 1/(1-p) is folded into delta (pre-divided) and the epilogue scales
+                        const bool keep = ((drop_lots(drop_mix(k4[j], keyterm), lotmul) >> lot_shift) & 0xffffu) >= a.drop_thresh;
+                        pdv = keep ? p : 0.f;
+                        dpv = keep ? dpv : 0.f;
                     }
                     pd[i] = pdv;
                     ds[i] = p * (dpv - d4[j]);
@@ -613,14 +637,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a) 
         __syncthreads();
     }
     // tiles: rows = key (registers), col = d (lane)
+    const float ks = DROP ? a.keep_scale : 1.f;
 #pragma unroll
     for (int dt = 0; dt < D / 32; ++dt)
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int kk = k0 + acc_row(i, h);
             if (kk < a.Nk) {
-                dkp[(int64_t)kk * a.dk_sn + 32 * dt + r] = from_f<T>(dk[dt][i] * a.scale);
-                dvp[(int64_t)kk * a.dv_sn + 32 * dt + r] = from_f<T>(dv[dt][i]);
+                dkp[(int64_t)kk * a.dk_sn + 32 * dt + r] = from_f<T>(dk[dt][i] * a.scale * ks);
+                dvp[(int64_t)kk * a.dv_sn + 32 * dt + r] = from_f<T>(dv[dt][i] * ks);
             }
         }
 }
