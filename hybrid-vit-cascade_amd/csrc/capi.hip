@@ -298,13 +298,13 @@ int hvc_col2im(const void* dcol, void* dsrc, int B, int C, int SD, int SH, int S
     return hip_result(hvc::col2im_launch(g, dcol, dsrc, dtype == HVC_BF16, (hipStream_t)stream), "col2im");
 }
 
-int hvc_trilinear_fwd(const float* src, float* dst, int B, int d, int h, int w, int D, int H, int W, void* stream) {
+int hvc_trilinear_fwd(const float* src, float* dst, int B, int d, int h, int w, int D, int H, int W, int align_corners, void* stream) {
     if (!src || !dst || B < 1 || d < 1 || h < 1 || w < 1 || D < 1 || H < 1 || W < 1) return fail(HVC_E_BADARG, "trilinear: bad operand");
-    return hip_result(hvc::trilinear_launch(src, dst, B, d, h, w, D, H, W, false, (hipStream_t)stream), "trilinear_fwd");
+    return hip_result(hvc::trilinear_launch(src, dst, B, d, h, w, D, H, W, align_corners != 0, false, (hipStream_t)stream), "trilinear_fwd");
 }
-int hvc_trilinear_bwd(const float* dout, float* dsrc, int B, int d, int h, int w, int D, int H, int W, void* stream) {
+int hvc_trilinear_bwd(const float* dout, float* dsrc, int B, int d, int h, int w, int D, int H, int W, int align_corners, void* stream) {
     if (!dout || !dsrc || B < 1 || d < 1 || h < 1 || w < 1 || D < 1 || H < 1 || W < 1) return fail(HVC_E_BADARG, "trilinear: bad operand");
-    return hip_result(hvc::trilinear_launch(dout, dsrc, B, d, h, w, D, H, W, true, (hipStream_t)stream), "trilinear_bwd");
+    return hip_result(hvc::trilinear_launch(dout, dsrc, B, d, h, w, D, H, W, align_corners != 0, true, (hipStream_t)stream), "trilinear_bwd");
 }
 
 static bool norm_c_ok(int C) { return C >= 8 && C <= 512 && C % 8 == 0 && 256 % (C / 8) == 0; }
@@ -314,19 +314,20 @@ int64_t hvc_norm_workspace(int B, int P, int C, int G) {
     return (int64_t)B * hvc::norm_chunks(P) * 2 * C + 2 * (int64_t)B * G + 2 * (int64_t)C;
 }
 
-int hvc_groupnorm_silu_fwd(const void* x, void* y, const float* gamma, const float* beta, float* stats, float* workspace,
-                           int B, int P, int C, int G, float eps, int dtype, void* stream) {
+int hvc_groupnorm_act_fwd(const void* x, void* y, const float* gamma, const float* beta, float* stats, float* workspace,
+                          int B, int P, int C, int G, float eps, int act, int dtype, void* stream) {
     if (!x || !y || !gamma || !beta || !stats || !workspace || !dtype_ok(dtype)) return fail(HVC_E_BADARG, "groupnorm: bad operand");
     if (B < 1 || P < 1 || G < 1 || C % G) return fail(HVC_E_BADARG, "groupnorm: bad shape");
     if (!norm_c_ok(C)) return fail(HVC_E_UNSUPPORTED, "groupnorm: C must be 8,16,32,64,128,256 or 512");
     hvc::NormArgs a; memset(&a, 0, sizeof(a));
     a.x = x; a.y = y; a.gamma = gamma; a.beta = beta; a.stats = stats; a.partial = workspace;
-    a.B = B; a.P = P; a.C = C; a.G = G; a.eps = eps; a.is_bf16 = dtype == HVC_BF16;
+    if (act != 0 && act != 1) return fail(HVC_E_BADARG, "groupnorm: act must be 0 (SiLU) or 1 (GELU)");
+    a.B = B; a.P = P; a.C = C; a.G = G; a.eps = eps; a.is_bf16 = dtype == HVC_BF16; a.act = act;
     return hip_result(hvc::groupnorm_silu_fwd_launch(a, (hipStream_t)stream), "groupnorm_silu_fwd");
 }
 
-int hvc_groupnorm_silu_bwd(const void* x, const void* dy, void* dx, const float* gamma, const float* beta, const float* stats,
-                           float* dgamma, float* dbeta, float* workspace, int B, int P, int C, int G, int dtype, void* stream) {
+int hvc_groupnorm_act_bwd(const void* x, const void* dy, void* dx, const float* gamma, const float* beta, const float* stats,
+                          float* dgamma, float* dbeta, float* workspace, int B, int P, int C, int G, int act, int dtype, void* stream) {
     if (!x || !dy || !dx || !gamma || !beta || !stats || !dgamma || !dbeta || !workspace || !dtype_ok(dtype))
         return fail(HVC_E_BADARG, "groupnorm_bwd: bad operand");
     if (B < 1 || P < 1 || G < 1 || C % G) return fail(HVC_E_BADARG, "groupnorm: bad shape");
@@ -335,7 +336,8 @@ int hvc_groupnorm_silu_bwd(const void* x, const void* dy, void* dx, const float*
     a.x = x; a.dy = dy; a.dx = dx; a.gamma = gamma; a.beta = beta; a.stats = const_cast<float*>(stats);
     a.dgamma = dgamma; a.dbeta = dbeta; a.partial = workspace;
     a.gsum = workspace + (int64_t)B * hvc::norm_chunks(P) * 2 * C;
-    a.B = B; a.P = P; a.C = C; a.G = G; a.is_bf16 = dtype == HVC_BF16;
+    if (act != 0 && act != 1) return fail(HVC_E_BADARG, "groupnorm: act must be 0 (SiLU) or 1 (GELU)");
+    a.B = B; a.P = P; a.C = C; a.G = G; a.is_bf16 = dtype == HVC_BF16; a.act = act;
     return hip_result(hvc::groupnorm_silu_bwd_launch(a, (hipStream_t)stream), "groupnorm_silu_bwd");
 }
 

@@ -134,7 +134,8 @@ struct ConvGeom {
 };
 hipError_t im2col_launch(const ConvGeom& g, const void* src, void* col, int is_bf16, hipStream_t st);
 hipError_t col2im_launch(const ConvGeom& g, const void* dcol, void* dsrc, int is_bf16, hipStream_t st);
-hipError_t trilinear_launch(const float* src, float* dst, int B, int d, int h, int w, int D, int H, int W, bool bwd, hipStream_t st);
+hipError_t trilinear_launch(const float* src, float* dst, int B, int d, int h, int w, int D, int H, int W, bool align_corners, bool bwd,
+                            hipStream_t st);
 
 struct PoolGeom { int N, H, W, C, HP, WP, k, s, p; };
 struct NormArgs {
@@ -149,6 +150,7 @@ struct NormArgs {
     int B, P, C, G;
     float eps, momentum;
     int training, is_bf16;
+    int act;                 // GroupNorm epilogue activation: 0 SiLU, 1 GELU(erf)
 };
 int norm_chunks(int P);
 hipError_t groupnorm_silu_fwd_launch(const NormArgs& a, hipStream_t st);

@@ -144,12 +144,19 @@ __device__ __forceinline__ float silu_grad_f(float z) {
     const float s = 1.f / (1.f + __expf(-z));
     return s * (1.f + z * (1.f - s));
 }
+// act: 0 = SiLU (voxel-embed stem), 1 = GELU(erf) (cascade glue: model_progressive.py:37-51, 169-174)
+__device__ __forceinline__ float act_f(float z, int act) {
+    return act == 0 ? silu_f(z) : 0.5f * z * (1.f + erff(z * 0.70710678118654752f));
+}
+__device__ __forceinline__ float act_grad_f(float z, int act) {
+    return act == 0 ? silu_grad_f(z) : 0.5f * (1.f + erff(z * 0.70710678118654752f)) + z * 0.3989422804014327f * __expf(-0.5f * z * z);
+}
 
 // ---- GroupNorm + SiLU apply ---------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void gn_silu_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, const float* __restrict__ stats,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                           int B, int P, int C, int G) {
+                                                           int B, int P, int C, int G, int act) {
     const int c8n = C / 8, cg = C / G;
     const int64_t total = (int64_t)B * P * c8n;
     for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
@@ -161,7 +168,7 @@ __global__ __launch_bounds__(256) void gn_silu_fwd_kernel(const T* __restrict__ 
         for (int j = 0; j < 8; ++j) {
             const int c = c8 * 8 + j, g = c / cg;
             const float mean = stats[2 * (b * G + g)], rstd = stats[2 * (b * G + g) + 1];
-            v[j] = silu_f((v[j] - mean) * rstd * gamma[c] + beta[c]);
+            v[j] = act_f((v[j] - mean) * rstd * gamma[c] + beta[c], act);
         }
         store8<T>(y + idx * 8, v);
     }
@@ -171,7 +178,7 @@ __global__ __launch_bounds__(256) void gn_silu_fwd_kernel(const T* __restrict__ 
 template <typename T>
 __global__ __launch_bounds__(256) void gn_silu_bwd_reduce_kernel(const T* __restrict__ x, const T* __restrict__ dy, const float* __restrict__ stats,
                                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                                  float* __restrict__ partial, int P, int C, int G, int nchunk) {
+                                                                  float* __restrict__ partial, int P, int C, int G, int nchunk, int act) {
     __shared__ float red[2 * 8 * kMaxC];
     __shared__ float out[2 * kMaxC];
     const int b = blockIdx.y, chunk = blockIdx.x, cg = C / G;
@@ -185,7 +192,7 @@ __global__ __launch_bounds__(256) void gn_silu_bwd_reduce_kernel(const T* __rest
         for (int j = 0; j < 8; ++j) {
             const int c = c8 * 8 + j, g = c / cg;
             const float xh = (xv[j] - stats[2 * (b * G + g)]) * stats[2 * (b * G + g) + 1];
-            const float ds = dv[j] * silu_grad_f(xh * gamma[c] + beta[c]);
+            const float ds = dv[j] * act_grad_f(xh * gamma[c] + beta[c], act);
             u[j] = ds;
             v[j] = ds * xh;
         }
@@ -219,7 +226,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void gn_silu_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx,
                                                                  const float* __restrict__ stats, const float* __restrict__ gsum,
                                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                                 int B, int P, int C, int G) {
+                                                                 int B, int P, int C, int G, int act) {
     const int c8n = C / 8, cg = C / G;
     const float inv_n = 1.f / ((float)P * cg);
     const int64_t total = (int64_t)B * P * c8n;
@@ -234,7 +241,7 @@ __global__ __launch_bounds__(256) void gn_silu_bwd_apply_kernel(const T* __restr
             const int c = c8 * 8 + j, g = c / cg, sg = b * G + g;
             const float rstd = stats[2 * sg + 1];
             const float xh = (xv[j] - stats[2 * sg]) * rstd;
-            const float ds = dv[j] * silu_grad_f(xh * gamma[c] + beta[c]);
+            const float ds = dv[j] * act_grad_f(xh * gamma[c] + beta[c], act);
             o[j] = rstd * (ds * gamma[c] - (gsum[2 * sg] + xh * gsum[2 * sg + 1]) * inv_n);
         }
         store8<T>(dx + idx * 8, o);
@@ -420,7 +427,7 @@ hipError_t groupnorm_silu_fwd_launch(const NormArgs& a, hipStream_t st) {
     HVC_DISPATCH_T(a.is_bf16, hipLaunchKernelGGL(chan_stats_kernel<T>, dim3(nch, a.B), dim3(256), 0, st, (const T*)a.x, a.partial, a.P, a.C, nch));
     hipLaunchKernelGGL(gn_finish_kernel, dim3((a.B * a.G + 255) / 256), dim3(256), 0, st, a.partial, a.stats, a.B, a.P, a.C, a.G, nch, a.eps);
     HVC_DISPATCH_T(a.is_bf16, hipLaunchKernelGGL(gn_silu_fwd_kernel<T>, dim3(grid_for((int64_t)a.B * a.P * a.C / 8)), dim3(256), 0, st,
-                                                 (const T*)a.x, (T*)a.y, a.stats, a.gamma, a.beta, a.B, a.P, a.C, a.G));
+                                                 (const T*)a.x, (T*)a.y, a.stats, a.gamma, a.beta, a.B, a.P, a.C, a.G, a.act));
     return hipGetLastError();
 }
 
@@ -428,11 +435,11 @@ hipError_t groupnorm_silu_bwd_launch(const NormArgs& a, hipStream_t st) {
     if (a.C % 8 || a.C > kMaxC || 256 % (a.C / 8) || a.C % a.G) return hipErrorInvalidValue;
     const int nch = norm_chunks(a.P);
     HVC_DISPATCH_T(a.is_bf16, hipLaunchKernelGGL(gn_silu_bwd_reduce_kernel<T>, dim3(nch, a.B), dim3(256), 0, st, (const T*)a.x, (const T*)a.dy,
-                                                 a.stats, a.gamma, a.beta, a.partial, a.P, a.C, a.G, nch));
+                                                 a.stats, a.gamma, a.beta, a.partial, a.P, a.C, a.G, nch, a.act));
     hipLaunchKernelGGL(gn_bwd_finish_kernel, dim3((a.C + a.B * a.G + 255) / 256), dim3(256), 0, st, a.partial, a.gamma, a.dgamma, a.dbeta,
                        a.gsum, a.B, a.C, a.G, nch);
     HVC_DISPATCH_T(a.is_bf16, hipLaunchKernelGGL(gn_silu_bwd_apply_kernel<T>, dim3(grid_for((int64_t)a.B * a.P * a.C / 8)), dim3(256), 0, st,
-                                                 (const T*)a.x, (const T*)a.dy, (T*)a.dx, a.stats, a.gsum, a.gamma, a.beta, a.B, a.P, a.C, a.G));
+                                                 (const T*)a.x, (const T*)a.dy, (T*)a.dx, a.stats, a.gsum, a.gamma, a.beta, a.B, a.P, a.C, a.G, a.act));
     return hipGetLastError();
 }
 

@@ -11,7 +11,8 @@
 // Backward: dcol = dOut W (GEMM, W read in place) -> col2im gather (deterministic, no atomics);
 // dW = dOut^T col (split-K GEMM).
 //
-// Also here: trilinear upsample with align_corners=True (reference models/hybrid_vit_backbone.py:272),
+// Also here: trilinear resize (align_corners=True: reference models/hybrid_vit_backbone.py:272; False: the
+// cascade's nn.Upsample / F.interpolate, model_progressive.py:170,211,239,294),
 // forward as a gather and backward as an output-stationary gather (each coarse voxel sums the
 // fine voxels in its support: deterministic, no atomics).
 #include "hvc_common.hip.h"
@@ -129,17 +130,29 @@ __global__ __launch_bounds__(256) void col2im_kernel(const ConvGeom g, const T* 
     }
 }
 
-// ---- trilinear, align_corners = True, single channel volumes [B][d][h][w] -> [B][D][H][W] ----------
-__device__ __forceinline__ float ac_scale(int in, int out) { return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f; }
+// ---- trilinear resize of single channel volumes [B][d][h][w] -> [B][D][H][W] ------------------------
+// Source coordinate of fine index o (ATen area_pixel_compute_source_index):
+//   align_corners : o * (in-1)/(out-1)        else : max(0, (o + 0.5) * in/out - 0.5)
+struct AxisMap {
+    float r;
+    int ac;
+    __device__ __forceinline__ float src(int o) const { return ac ? r * o : fmaxf(r * (o + 0.5f) - 0.5f, 0.f); }
+};
+__device__ __forceinline__ AxisMap axis_map(int in, int out, int ac) {
+    AxisMap m;
+    m.ac = ac;
+    m.r = ac ? (out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f) : (float)in / (float)out;
+    return m;
+}
 
 __global__ __launch_bounds__(256) void trilinear_fwd_kernel(const float* __restrict__ src, float* __restrict__ dst,
-                                                             int B, int d, int h, int w, int D, int H, int W) {
-    const float rd = ac_scale(d, D), rh = ac_scale(h, H), rw = ac_scale(w, W);
+                                                             int B, int d, int h, int w, int D, int H, int W, int ac) {
+    const AxisMap md = axis_map(d, D, ac), mh = axis_map(h, H, ac), mw = axis_map(w, W, ac);
     const int64_t total = (int64_t)B * D * H * W;
     for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
         const Pos o = decode(idx, D, H, W);
-        const float fd = rd * o.d, fh = rh * o.h, fw = rw * o.w;
-        const int d0 = (int)fd, h0 = (int)fh, w0 = (int)fw;
+        const float fd = md.src(o.d), fh = mh.src(o.h), fw = mw.src(o.w);
+        const int d0 = min((int)fd, d - 1), h0 = min((int)fh, h - 1), w0 = min((int)fw, w - 1);
         const int d1 = min(d0 + 1, d - 1), h1 = min(h0 + 1, h - 1), w1 = min(w0 + 1, w - 1);
         const float ld = fd - d0, lh = fh - h0, lw = fw - w0;
         const float* s = src + (int64_t)o.b * d * h * w;
@@ -151,9 +164,9 @@ __global__ __launch_bounds__(256) void trilinear_fwd_kernel(const float* __restr
 }
 
 // weight of fine index o onto coarse index i along one axis (mirrors the forward's i0 / i1 / lambda)
-__device__ __forceinline__ float axis_w(int o, int i, float r, int in) {
-    const float f = r * o;
-    const int i0 = (int)f;
+__device__ __forceinline__ float axis_w(int o, int i, const AxisMap& m, int in) {
+    const float f = m.src(o);
+    const int i0 = min((int)f, in - 1);
     const int i1 = min(i0 + 1, in - 1);
     const float l = f - i0;
     float wgt = 0.f;
@@ -161,33 +174,34 @@ __device__ __forceinline__ float axis_w(int o, int i, float r, int in) {
     if (i == i1) wgt += l;
     return wgt;
 }
-__device__ __forceinline__ void axis_range(int i, float r, int in, int out, int& lo, int& hi) {
-    if (r <= 0.f) { lo = 0; hi = out - 1; return; }
-    lo = max(0, (int)floorf((i - 1) / r) - 1);
-    hi = min(out - 1, (int)ceilf((i + 1) / r) + 1);
+// conservative range of fine indices whose support can include coarse index i
+__device__ __forceinline__ void axis_range(int i, const AxisMap& m, int out, int& lo, int& hi) {
+    if (m.r <= 0.f) { lo = 0; hi = out - 1; return; }
+    lo = max(0, (int)floorf((i - 1) / m.r) - 2);
+    hi = min(out - 1, (int)ceilf((i + 1) / m.r) + 2);
 }
 
 __global__ __launch_bounds__(256) void trilinear_bwd_kernel(const float* __restrict__ dout, float* __restrict__ dsrc,
-                                                             int B, int d, int h, int w, int D, int H, int W) {
-    const float rd = ac_scale(d, D), rh = ac_scale(h, H), rw = ac_scale(w, W);
+                                                             int B, int d, int h, int w, int D, int H, int W, int ac) {
+    const AxisMap md = axis_map(d, D, ac), mh = axis_map(h, H, ac), mw = axis_map(w, W, ac);
     const int64_t total = (int64_t)B * d * h * w;
     for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
         const Pos s = decode(idx, d, h, w);
         int dlo, dhi, hlo, hhi, wlo, whi;
-        axis_range(s.d, rd, d, D, dlo, dhi);
-        axis_range(s.h, rh, h, H, hlo, hhi);
-        axis_range(s.w, rw, w, W, wlo, whi);
+        axis_range(s.d, md, D, dlo, dhi);
+        axis_range(s.h, mh, H, hlo, hhi);
+        axis_range(s.w, mw, W, wlo, whi);
         const float* g = dout + (int64_t)s.b * D * H * W;
         float acc = 0.f;
         for (int od = dlo; od <= dhi; ++od) {
-            const float wd = axis_w(od, s.d, rd, d);
+            const float wd = axis_w(od, s.d, md, d);
             if (wd == 0.f) continue;
             for (int oh = hlo; oh <= hhi; ++oh) {
-                const float wh = axis_w(oh, s.h, rh, h);
+                const float wh = axis_w(oh, s.h, mh, h);
                 if (wh == 0.f) continue;
                 float row = 0.f;
                 for (int ow = wlo; ow <= whi; ++ow) {
-                    const float ww = axis_w(ow, s.w, rw, w);
+                    const float ww = axis_w(ow, s.w, mw, w);
                     if (ww != 0.f) row += ww * g[((int64_t)od * H + oh) * W + ow];
                 }
                 acc += wd * wh * row;
@@ -235,9 +249,11 @@ hipError_t col2im_launch(const ConvGeom& g, const void* dcol, void* dsrc, int is
     return hipGetLastError();
 }
 
-hipError_t trilinear_launch(const float* src, float* dst, int B, int d, int h, int w, int D, int H, int W, bool bwd, hipStream_t st) {
-    if (!bwd) hipLaunchKernelGGL(trilinear_fwd_kernel, dim3(grid_for((int64_t)B * D * H * W)), dim3(256), 0, st, src, dst, B, d, h, w, D, H, W);
-    else hipLaunchKernelGGL(trilinear_bwd_kernel, dim3(grid_for((int64_t)B * d * h * w)), dim3(256), 0, st, src, dst, B, d, h, w, D, H, W);
+hipError_t trilinear_launch(const float* src, float* dst, int B, int d, int h, int w, int D, int H, int W, bool align_corners, bool bwd,
+                            hipStream_t st) {
+    const int ac = align_corners ? 1 : 0;
+    if (!bwd) hipLaunchKernelGGL(trilinear_fwd_kernel, dim3(grid_for((int64_t)B * D * H * W)), dim3(256), 0, st, src, dst, B, d, h, w, D, H, W, ac);
+    else hipLaunchKernelGGL(trilinear_bwd_kernel, dim3(grid_for((int64_t)B * d * h * w)), dim3(256), 0, st, src, dst, B, d, h, w, D, H, W, ac);
     return hipGetLastError();
 }
 

@@ -36,11 +36,11 @@ SIGNATURES = {
     "hvc_cast": (_i, [_p, _p, _i64, _i, _i, _p]),
     "hvc_im2col": (_i, [_p, _p] + [_i] * 12 + [_i64, _i, _p]),
     "hvc_col2im": (_i, [_p, _p] + [_i] * 12 + [_i64, _i, _p]),
-    "hvc_trilinear_fwd": (_i, [_p, _p] + [_i] * 7 + [_p]),
-    "hvc_trilinear_bwd": (_i, [_p, _p] + [_i] * 7 + [_p]),
+    "hvc_trilinear_fwd": (_i, [_p, _p] + [_i] * 8 + [_p]),
+    "hvc_trilinear_bwd": (_i, [_p, _p] + [_i] * 8 + [_p]),
     "hvc_norm_workspace": (_i64, [_i, _i, _i, _i]),
-    "hvc_groupnorm_silu_fwd": (_i, [_p] * 6 + [_i, _i, _i, _i, _f, _i, _p]),
-    "hvc_groupnorm_silu_bwd": (_i, [_p] * 9 + [_i, _i, _i, _i, _i, _p]),
+    "hvc_groupnorm_act_fwd": (_i, [_p] * 6 + [_i, _i, _i, _i, _f, _i, _i, _p]),
+    "hvc_groupnorm_act_bwd": (_i, [_p] * 9 + [_i, _i, _i, _i, _i, _i, _p]),
     "hvc_bn_relu_pool_fwd": (_i, [_p] * 9 + [_i] * 8 + [_f, _f, _i, _p]),
     "hvc_bn_relu_pool_bwd": (_i, [_p] * 10 + [_i] * 8 + [_i, _p]),
     "hvc_ssim_l1_workspace": (_i64, [_i, _i, _i, _i]),

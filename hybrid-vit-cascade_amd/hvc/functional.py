@@ -413,15 +413,15 @@ class ConvFn(torch.autograd.Function):
 
 
 class GroupNormSiluFn(torch.autograd.Function):
-    """GroupNorm(G) + SiLU on channels-last (B, ..., C)."""
+    """GroupNorm(G) + activation (ops.ACT_SILU / ops.ACT_GELU_ERF) on channels-last (B, ..., C)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, G, eps):
+    def forward(ctx, x, gamma, beta, G, eps, act=0):
         shp = x.shape
         x3 = x.detach().contiguous().view(shp[0], -1, shp[-1])
-        y, stats = ops.groupnorm_silu_fwd(x3, _f32(gamma), _f32(beta), G, eps)
+        y, stats = ops.groupnorm_silu_fwd(x3, _f32(gamma), _f32(beta), G, eps, act)
         ctx.save_for_backward(x3, gamma, beta, stats)
-        ctx.G = G
+        ctx.G, ctx.act = G, act
         return y.view(shp)
 
     @staticmethod
@@ -430,8 +430,8 @@ class GroupNormSiluFn(torch.autograd.Function):
         dyc = dy.reshape(x3.shape)
         if dyc.dtype != x3.dtype:
             dyc = ops.cast(dyc, x3.dtype)
-        dx, dg, db = ops.groupnorm_silu_bwd(x3, dyc, _f32(gamma), _f32(beta), stats, ctx.G)
-        return dx.view(dy.shape), dg, db, None, None
+        dx, dg, db = ops.groupnorm_silu_bwd(x3, dyc, _f32(gamma), _f32(beta), stats, ctx.G, ctx.act)
+        return dx.view(dy.shape), dg, db, None, None, None
 
 
 class BnReluPoolFn(torch.autograd.Function):
@@ -455,19 +455,19 @@ class BnReluPoolFn(torch.autograd.Function):
 
 
 class TrilinearFn(torch.autograd.Function):
-    """(B, 1, d, h, w) fp32 -> (B, 1, D, H, W), align_corners=True."""
+    """(B, 1, d, h, w) fp32 -> (B, 1, D, H, W)."""
 
     @staticmethod
-    def forward(ctx, x, size):
+    def forward(ctx, x, size, align_corners=True):
         B = x.shape[0]
-        ctx.in_size = tuple(x.shape[2:])
-        return ops.trilinear_fwd(_f32(x).view(B, *ctx.in_size), tuple(size)).view(B, 1, *size)
+        ctx.in_size, ctx.ac = tuple(x.shape[2:]), bool(align_corners)
+        return ops.trilinear_fwd(_f32(x).view(B, *ctx.in_size), tuple(size), ctx.ac).view(B, 1, *size)
 
     @staticmethod
     def backward(ctx, dy):
         B = dy.shape[0]
-        dx = ops.trilinear_bwd(_f32(dy).view(B, *dy.shape[2:]), ctx.in_size)
-        return dx.view(B, 1, *ctx.in_size), None
+        dx = ops.trilinear_bwd(_f32(dy).view(B, *dy.shape[2:]), ctx.in_size, ctx.ac)
+        return dx.view(B, 1, *ctx.in_size), None, None
 
 
 class SsimL1LossFn(torch.autograd.Function):

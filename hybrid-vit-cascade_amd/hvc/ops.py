@@ -348,22 +348,22 @@ def col2im(dcol, geom):
     return dx
 
 
-def trilinear_fwd(x, size):
-    """x: (B, d, h, w) fp32 contiguous -> (B, D, H, W), align_corners=True."""
+def trilinear_fwd(x, size, align_corners=True):
+    """x: (B, d, h, w) fp32 contiguous -> (B, D, H, W)."""
     _dev(x)
     _f32c(x, "x")
     B, d, h, w = x.shape
     y = torch.empty((B, *size), dtype=torch.float32, device=x.device)
-    check(_lib.load().hvc_trilinear_fwd(x.data_ptr(), y.data_ptr(), B, d, h, w, *size, _stream()), "hvc_trilinear_fwd")
+    check(_lib.load().hvc_trilinear_fwd(x.data_ptr(), y.data_ptr(), B, d, h, w, *size, int(align_corners), _stream()), "hvc_trilinear_fwd")
     return y
 
 
-def trilinear_bwd(dy, in_size):
+def trilinear_bwd(dy, in_size, align_corners=True):
     _dev(dy)
     _f32c(dy, "dy")
     B, D, H, W = dy.shape
     dx = torch.empty((B, *in_size), dtype=torch.float32, device=dy.device)
-    check(_lib.load().hvc_trilinear_bwd(dy.data_ptr(), dx.data_ptr(), B, *in_size, D, H, W, _stream()), "hvc_trilinear_bwd")
+    check(_lib.load().hvc_trilinear_bwd(dy.data_ptr(), dx.data_ptr(), B, *in_size, D, H, W, int(align_corners), _stream()), "hvc_trilinear_bwd")
     return dx
 
 
@@ -372,7 +372,10 @@ def _norm_ws(B, P, C, G, device):
     return torch.empty((n,), dtype=torch.float32, device=device)
 
 
-def groupnorm_silu_fwd(x, gamma, beta, G, eps=1e-5):
+ACT_SILU, ACT_GELU_ERF = 0, 1
+
+
+def groupnorm_silu_fwd(x, gamma, beta, G, eps=1e-5, act=ACT_SILU):
     """x: (B, P, C) channels-last contiguous.  Returns y, stats (B, G, 2)."""
     _dev(x, gamma, beta)
     B, P, Cn = x.shape
@@ -381,22 +384,22 @@ def groupnorm_silu_fwd(x, gamma, beta, G, eps=1e-5):
     y = torch.empty_like(x)
     stats = torch.empty((B, G, 2), dtype=torch.float32, device=x.device)
     ws = _norm_ws(B, P, Cn, G, x.device)
-    check(_lib.load().hvc_groupnorm_silu_fwd(x.data_ptr(), y.data_ptr(), _f32c(gamma, "gamma").data_ptr(), _f32c(beta, "beta").data_ptr(),
-                                             stats.data_ptr(), ws.data_ptr(), B, P, Cn, G, float(eps), _code(x.dtype), _stream()),
-          "hvc_groupnorm_silu_fwd")
+    check(_lib.load().hvc_groupnorm_act_fwd(x.data_ptr(), y.data_ptr(), _f32c(gamma, "gamma").data_ptr(), _f32c(beta, "beta").data_ptr(),
+                                            stats.data_ptr(), ws.data_ptr(), B, P, Cn, G, float(eps), int(act), _code(x.dtype), _stream()),
+          "hvc_groupnorm_act_fwd")
     return y, stats
 
 
-def groupnorm_silu_bwd(x, dy, gamma, beta, stats, G):
+def groupnorm_silu_bwd(x, dy, gamma, beta, stats, G, act=ACT_SILU):
     _dev(x, dy, gamma, beta, stats)
     B, P, Cn = x.shape
     dy = dy.contiguous()
     dx = torch.empty_like(x)
     dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(beta)
     ws = _norm_ws(B, P, Cn, G, x.device)
-    check(_lib.load().hvc_groupnorm_silu_bwd(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), gamma.data_ptr(), beta.data_ptr(), stats.data_ptr(),
-                                             dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), B, P, Cn, G, _code(x.dtype), _stream()),
-          "hvc_groupnorm_silu_bwd")
+    check(_lib.load().hvc_groupnorm_act_bwd(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), gamma.data_ptr(), beta.data_ptr(), stats.data_ptr(),
+                                            dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), B, P, Cn, G, int(act), _code(x.dtype), _stream()),
+          "hvc_groupnorm_act_bwd")
     return dx, dgamma, dbeta
 
 

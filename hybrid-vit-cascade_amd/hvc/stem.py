@@ -25,7 +25,11 @@ STAGE_BACKEND = {
     "xray_batchnorm_relu_pool": "hip",
     "xray_view_mean_gap": "aten",
     "ssim_l1_loss": "hip",
+    "cascade_glue_conv_gn_gelu_upsample": "hip (aten conv above the im2col memory cap)",
 }
+
+IM2COL_CAP_BYTES = 6 << 30     # patch matrices above this fall back to the ATen convolution (chunked im2col: next round)
+_warned_cap = False
 
 
 def _require_gpu(t):
@@ -41,12 +45,73 @@ def _channels_last(x):
     return x.permute(*perm).contiguous()
 
 
-def voxel_tokens(voxel_embed, x, pos_embed):
-    """(B,Cin,D,H,W) -> (B,N,C) fp32 tokens, n = (d*H'+h)*W'+w, + pos_embed
+def conv_channels_last(h, layer, cdt, out_dtype=None, addvec=None):
+    """nn.Conv3d / nn.Conv2d on a channels-last tensor (B, D, H, W, C) (2-D: D = 1) -> channels-last."""
+    global _warned_cap
+    is3d = isinstance(layer, nn.Conv3d)
+    ks = layer.kernel_size if is3d else (1, *layer.kernel_size)
+    pad = layer.padding if is3d else (0, *layer.padding)
+    if len(set(layer.stride)) != 1:
+        raise RuntimeError("HVC conv: anisotropic strides are not supported")
+    geom = ops.ConvGeometry(h.shape[0], layer.in_channels, h.shape[1:4], ks, layer.stride[0], pad)
+    out_dtype = out_dtype or cdt
+    if geom.M * geom.Kp * (2 if cdt == torch.bfloat16 else 4) > IM2COL_CAP_BYTES:
+        if not _warned_cap:
+            print(f"[hvc] conv {layer.in_channels}->{layer.out_channels} on {tuple(h.shape[1:4])}: patch matrix above "
+                  f"{IM2COL_CAP_BYTES >> 30} GiB, using the ATen convolution for this layer")
+            _warned_cap = True
+        with torch.autocast("cuda", enabled=False):
+            x = h.float().permute(0, 4, 1, 2, 3)
+            y = torch.nn.functional.conv3d(x, layer.weight if is3d else layer.weight.unsqueeze(2), layer.bias,
+                                           stride=layer.stride[0], padding=pad)
+        y = y.permute(0, 2, 3, 4, 1)
+        if addvec is not None:
+            y = y + addvec.reshape(1, *y.shape[1:])
+        return y.to(out_dtype).contiguous()
+    return HF.ConvFn.apply(h, layer.weight, layer.bias, addvec, geom, cdt, out_dtype)
+
+
+def glue_sequential(seq, h, cdt):
+    """Walks an nn.Sequential of {Upsample(trilinear x2), Conv2d/Conv3d, GroupNorm + GELU/SiLU} on a
+    channels-last tensor (B, D, H, W, C) -- the cascade glue of model_progressive.py:37-51,169-174,238-243,259-267."""
+    layers = list(seq)
+    i = 0
+    while i < len(layers):
+        layer = layers[i]
+        if isinstance(layer, nn.Upsample):
+            if h.shape[-1] != 1 or layer.mode != "trilinear":
+                raise RuntimeError("HVC glue: only single-channel trilinear upsampling is supported")
+            sf = layer.scale_factor
+            size = tuple(int(d * sf) for d in h.shape[1:4])
+            v = HF.TrilinearFn.apply(h.reshape(h.shape[0], 1, *h.shape[1:4]).float(), size, bool(layer.align_corners))
+            h = v.reshape(v.shape[0], *size, 1)
+            i += 1
+        elif isinstance(layer, (nn.Conv3d, nn.Conv2d)):
+            h = conv_channels_last(h, layer, cdt)
+            i += 1
+        elif isinstance(layer, nn.GroupNorm):
+            nxt = layers[i + 1] if i + 1 < len(layers) else None
+            if isinstance(nxt, nn.GELU):
+                act = ops.ACT_GELU_ERF
+            elif isinstance(nxt, nn.SiLU):
+                act = ops.ACT_SILU
+            else:
+                raise RuntimeError("HVC glue: GroupNorm must be followed by GELU or SiLU")
+            if h.dtype != cdt:
+                h = h.to(cdt)
+            h = HF.GroupNormSiluFn.apply(h, layer.weight, layer.bias, layer.num_groups, layer.eps, act)
+            i += 2
+        else:
+            raise RuntimeError(f"unexpected layer in cascade glue: {type(layer).__name__}")
+    return h
+
+
+def voxel_tokens(voxel_embed, x, pos_embed, channels_last=False):
+    """(B,Cin,D,H,W) [or channels-last (B,D,H,W,Cin)] -> (B,N,C) fp32 tokens, n = (d*H'+h)*W'+w, + pos_embed
     (reference models/hybrid_vit_backbone.py:252-258)."""
     _require_gpu(x)
     cdt = HF.compute_dtype(x)
-    h = _channels_last(x)                                   # (B, D, H, W, Cin)
+    h = x if channels_last else _channels_last(x)           # (B, D, H, W, Cin)
     layers = list(voxel_embed)
     i = 0
     fused_pos = False
@@ -54,9 +119,7 @@ def voxel_tokens(voxel_embed, x, pos_embed):
         layer = layers[i]
         if isinstance(layer, nn.Conv3d):
             last = i == len(layers) - 1
-            geom = ops.ConvGeometry(h.shape[0], layer.in_channels, h.shape[1:4], layer.kernel_size, layer.stride[0], layer.padding)
-            h = HF.ConvFn.apply(h, layer.weight, layer.bias, pos_embed if last else None, geom, cdt,
-                                torch.float32 if last else cdt)
+            h = conv_channels_last(h, layer, cdt, torch.float32 if last else cdt, pos_embed if last else None)
             fused_pos = last
             i += 1
         elif isinstance(layer, nn.GroupNorm):

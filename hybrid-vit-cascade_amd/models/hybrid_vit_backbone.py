@@ -133,10 +133,11 @@ class HybridViT3D(nn.Module):
         self.output_proj = nn.Linear(voxel_dim, 1)
 
     def forward(self, x: torch.Tensor, context: torch.Tensor, cond: torch.Tensor,
-                prev_stage_embed: Optional[torch.Tensor] = None) -> torch.Tensor:
-        B = x.shape[0]
+                prev_stage_embed: Optional[torch.Tensor] = None, channels_last: bool = False) -> torch.Tensor:
+        """x: (B, Cin, D, H, W); with channels_last=True (build-only kwarg) x is (B, D, H, W, Cin), which
+        spares the cascade stages a layout copy."""
         Dd, Hd, Wd = self.downsampled_size
-        tokens = HS.voxel_tokens(self.voxel_embed, x, self.pos_embed)         # (B, N, C) fp32, n = (d*H'+h)*W'+w
+        tokens = HS.voxel_tokens(self.voxel_embed, x, self.pos_embed, channels_last)   # (B, N, C) fp32, n = (d*H'+h)*W'+w
         for block in self.blocks:
             tokens = block(tokens, context, cond, prev_stage_embed)
         vol = HS.token_head(tokens, self.norm, self.output_proj, (Dd, Hd, Wd))  # (B,1,D',H',W') fp32

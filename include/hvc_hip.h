@@ -177,22 +177,26 @@ int hvc_im2col(const void* src, void* col, int B, int C, int SD, int SH, int SW,
 int hvc_col2im(const void* dcol, void* dsrc, int B, int C, int SD, int SH, int SW, int KD, int KH, int KW,
                int stride, int PD, int PH, int PW, int64_t Kp, int dtype, void* stream);
 
-/* Trilinear resize of single-channel fp32 volumes [B][d][h][w] -> [B][D][H][W], align_corners=True
- * (F.interpolate at models/hybrid_vit_backbone.py:272) and its adjoint. */
-int hvc_trilinear_fwd(const float* src, float* dst, int B, int d, int h, int w, int D, int H, int W, void* stream);
-int hvc_trilinear_bwd(const float* dout, float* dsrc, int B, int d, int h, int w, int D, int H, int W, void* stream);
+/* Trilinear resize of single-channel fp32 volumes [B][d][h][w] -> [B][D][H][W] and its adjoint:
+ * align_corners=1 for F.interpolate at models/hybrid_vit_backbone.py:272; align_corners=0 for the cascade's
+ * nn.Upsample / F.interpolate (direct_regression/progressive_cascade/model_progressive.py:170,211,239,294). */
+int hvc_trilinear_fwd(const float* src, float* dst, int B, int d, int h, int w, int D, int H, int W,
+                      int align_corners, void* stream);
+int hvc_trilinear_bwd(const float* dout, float* dsrc, int B, int d, int h, int w, int D, int H, int W,
+                      int align_corners, void* stream);
 
 /* Floats of scratch for the four normalisation calls below. */
 int64_t hvc_norm_workspace(int B, int P, int C, int G);
 
-/* GroupNorm(G, C) + SiLU on channels-last x[B][P][C] (nn.GroupNorm + nn.SiLU at
- * models/hybrid_vit_backbone.py:199-200).  stats: [B][G][2] (mean, rstd), written by fwd, read by bwd.
- * C in {8,16,32,64,128,256,512}. */
-int hvc_groupnorm_silu_fwd(const void* x, void* y, const float* gamma, const float* beta, float* stats,
-                           float* workspace, int B, int P, int C, int G, float eps, int dtype, void* stream);
-int hvc_groupnorm_silu_bwd(const void* x, const void* dy, void* dx, const float* gamma, const float* beta,
-                           const float* stats, float* dgamma, float* dbeta, float* workspace,
-                           int B, int P, int C, int G, int dtype, void* stream);
+/* GroupNorm(G, C) + activation on channels-last x[B][P][C]: act 0 = SiLU (nn.GroupNorm + nn.SiLU at
+ * models/hybrid_vit_backbone.py:199-200), act 1 = GELU(erf) (cascade glue, model_progressive.py:39-40,
+ * 172-173).  stats: [B][G][2] (mean, rstd), written by fwd, read by bwd.  C in {8,16,32,64,128,256,512}. */
+int hvc_groupnorm_act_fwd(const void* x, void* y, const float* gamma, const float* beta, float* stats,
+                          float* workspace, int B, int P, int C, int G, float eps, int act, int dtype,
+                          void* stream);
+int hvc_groupnorm_act_bwd(const void* x, const void* dy, void* dx, const float* gamma, const float* beta,
+                          const float* stats, float* dgamma, float* dbeta, float* workspace,
+                          int B, int P, int C, int G, int act, int dtype, void* stream);
 
 /* BatchNorm2d + ReLU + MaxPool2d(k, s, p) on channels-last x[N][H][W][C] (models/diagnostic_losses.py:83-85,
  * 88-90, 93-94; k = 1 for the last, pool-less stage).  training: batch statistics, running_mean/var

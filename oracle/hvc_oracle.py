@@ -295,3 +295,55 @@ def psnr(pred: torch.Tensor, target: torch.Tensor) -> float:
     if mse == 0:
         return float("inf")
     return (20 * torch.log10(2.0 / torch.sqrt(mse))).item()
+
+
+# ------------------------------------------------------------------------------------------------
+# Progressive cascade glue  (direct_regression/progressive_cascade/model_progressive.py)
+# ------------------------------------------------------------------------------------------------
+def _conv_gn_gelu_2d(x, P, pre, idx, stride):
+    x = F.conv2d(x, P[f"{pre}{idx}.weight"], P[f"{pre}{idx}.bias"], stride=stride, padding=1)
+    x = F.group_norm(x, 32, P[f"{pre}{idx + 1}.weight"], P[f"{pre}{idx + 1}.bias"], 1e-5)
+    return F.gelu(x)
+
+
+def multiscale_xray_encoder(xrays: torch.Tensor, P: Params, pre: str, stage: int, training: bool = False):
+    """MultiScaleXrayEncoder.forward, model_progressive.py:54-83.  Returns (features_2d, time_xray_cond, xray_context)."""
+    B = xrays.shape[0]
+    t = torch.zeros(B, 256, dtype=xrays.dtype)
+    ctx, cond, f = xray_conditioning(xrays, t, P, pre + "xray_encoder.", training)
+    if stage == 1:                                                    # :74-76  two stride-2 conv+GN(32)+GELU
+        f = _conv_gn_gelu_2d(f, P, pre + "to_stage1.", 0, 2)
+        f = _conv_gn_gelu_2d(f, P, pre + "to_stage1.", 3, 2)
+    elif stage == 2:                                                  # :77-79
+        f = _conv_gn_gelu_2d(f, P, pre + "to_stage2.", 0, 2)
+    return f, cond, ctx
+
+
+def _upsample_stem(v, P, pre):
+    """nn.Upsample(x2, trilinear, align_corners=False) -> Conv3d(1,32,3,p1) -> GroupNorm(8,32) -> GELU (:169-174, :238-243)."""
+    x = F.interpolate(v, scale_factor=2, mode="trilinear", align_corners=False)
+    x = F.conv3d(x, P[pre + "1.weight"], P[pre + "1.bias"], padding=1)
+    return F.gelu(F.group_norm(x, 8, P[pre + "2.weight"], P[pre + "2.bias"], 1e-5))
+
+
+def stage2_refiner(v64, feats, cond, P: Params, pre: str, volume_size, voxel_dim, depth, heads, token_grid=None):
+    """Stage2Refiner128.forward, model_progressive.py:191-216."""
+    x = _upsample_stem(v64, P, pre + "upsample_from_64.")
+    ref = hybrid_vit3d(x, feats.flatten(2).transpose(1, 2), cond, P, pre + "vit_refiner.", volume_size, 32, voxel_dim,
+                       depth, heads, token_grid)
+    up = F.interpolate(v64, size=tuple(volume_size), mode="trilinear", align_corners=False)
+    return up + P[pre + "residual_weight"] * ref
+
+
+def stage3_refiner(v128, feats, cond, P: Params, pre: str, volume_size, voxel_dim, depth, heads):
+    """Stage3Refiner256.forward (no checkpointing), model_progressive.py:273-307."""
+    x = _upsample_stem(v128, P, pre + "upsample_from_128.")
+    ref = hybrid_vit3d(x, feats.flatten(2).transpose(1, 2), cond, P, pre + "vit_refiner.", volume_size, 32, voxel_dim,
+                       depth, heads)
+    up = F.interpolate(v128, size=tuple(volume_size), mode="trilinear", align_corners=False)
+    d = F.conv3d(up, P[pre + "detail_enhancer.0.weight"], P[pre + "detail_enhancer.0.bias"], padding=1)       # :259-267
+    d = F.gelu(F.group_norm(d, 16, P[pre + "detail_enhancer.1.weight"], P[pre + "detail_enhancer.1.bias"], 1e-5))
+    d = F.conv3d(d, P[pre + "detail_enhancer.3.weight"], P[pre + "detail_enhancer.3.bias"], padding=1)
+    d = F.gelu(F.group_norm(d, 8, P[pre + "detail_enhancer.4.weight"], P[pre + "detail_enhancer.4.bias"], 1e-5))
+    d = F.conv3d(d, P[pre + "detail_enhancer.6.weight"], P[pre + "detail_enhancer.6.bias"])
+    return up + P[pre + "residual_weight"] * ref + P[pre + "detail_weight"] * d                                 # :303-305

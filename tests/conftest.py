@@ -52,6 +52,13 @@ class Golden:
         pre = prefix + "/"
         return sorted({k[len(pre):].split("#")[0] for k in self.z.files if k.startswith(pre)})
 
+    def is_noise(self, prefix, name, floor=1e-6):
+        """True when the stored reference tensor is all rounding noise (a mathematically zero gradient,
+        e.g. a conv bias ahead of a normalisation that removes per-channel means)."""
+        key = f"{prefix}/{name}" if prefix else name
+        a = self.z[key] if key in self.z.files else self.z[key + "#probe"]
+        return float(np.abs(a).max()) < floor
+
     @staticmethod
     def _err(got, ref, metric):
         # floor: exactly-zero gradients (conv bias ahead of BatchNorm) hold only rounding noise

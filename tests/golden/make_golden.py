@@ -28,6 +28,7 @@ from models.hybrid_vit_backbone import HybridViTBlock3D, HybridViT3D  # noqa: E4
 from models.diagnostic_losses import XrayConditioningModule, DRRRenderer, ProjectionLoss  # noqa: E402
 from model_direct import DirectCTRegression, DirectRegressionLoss  # noqa: E402
 from loss_multiscale import DRRReprojectionLoss, compute_psnr  # noqa: E402
+from model_progressive import MultiScaleXrayEncoder, Stage2Refiner128, Stage3Refiner256  # noqa: E402
 
 OUT = os.path.dirname(os.path.abspath(__file__))
 torch.set_num_threads(8)
@@ -235,6 +236,36 @@ def direct_fixture():
     save("direct_small", arrays)
 
 
+def cascade_fixture():
+    """Stage 2 + stage 3 refiners and the shared multi-scale X-ray encoder at reduced sizes (16^3 -> 32^3 -> 64^3),
+    chained exactly as ProgressiveCascadeModel.forward does (model_progressive.py:388-400)."""
+    g = gen(606)
+    torch.manual_seed(16)
+    enc = MultiScaleXrayEncoder(img_size=64, in_channels=1, base_dim=32, num_views=2)
+    s2 = Stage2Refiner128(volume_size=(32, 32, 32), voxel_dim=32, vit_depth=1, num_heads=1, xray_feature_dim=32)
+    s3 = Stage3Refiner256(volume_size=(64, 64, 64), voxel_dim=32, vit_depth=1, num_heads=1, xray_feature_dim=32,
+                          use_gradient_checkpointing=False)
+    for m in (enc, s2, s3):
+        reinit_adaln(m, g)
+        m.eval()
+    xr = randn(g, 1, 2, 1, 64, 64)
+    v16 = (randn(g, 1, 1, 16, 16, 16) * 0.5).requires_grad_(True)
+    w2, w3 = randn(g, 1, 1, 32, 32, 32), randn(g, 1, 1, 64, 64, 64)
+    f1, c1, _ = enc(xr, stage=1)
+    f2, cond2, _ = enc(xr, stage=2)
+    v32 = s2(v16, f2, cond2)
+    f3, cond3, _ = enc(xr, stage=3)
+    v64 = s3(v32, f3, cond3)
+    for m in (enc, s2, s3):
+        m.zero_grad()
+    ((v32 * w2).sum() + (v64 * w3).sum() + f1.sum() * 0.1).backward()
+    save("cascade_small", dict(xrays=xr, v16=v16, w2=w2, w3=w3, feats1=f1, feats2=f2, v32=v32, v64=v64, dv16=v16.grad,
+                               enc_params=dict(enc.state_dict()), s2_params=dict(s2.state_dict()), s3_params=dict(s3.state_dict()),
+                               enc_pgrad={k: p.grad.clone() for k, p in enc.named_parameters() if p.grad is not None},
+                               s2_pgrad={k: p.grad.clone() for k, p in s2.named_parameters() if p.grad is not None},
+                               s3_pgrad={k: p.grad.clone() for k, p in s3.named_parameters() if p.grad is not None}))
+
+
 def direct_kat():
     """Full-size known answers: values only, no tensors."""
     torch.manual_seed(0)
@@ -258,3 +289,4 @@ if __name__ == "__main__":
     drr_fixtures()
     direct_fixture()
     direct_kat()
+    cascade_fixture()

@@ -36,6 +36,21 @@ def _zero_dropout(m):
             mod.p = 0.0
 
 
+def _zero_grad_biases(module):
+    """Names of conv biases that feed a GroupNorm with one channel per group (or a train-mode BatchNorm): the
+    normalisation removes the per-channel mean, so their gradient is exactly zero and both sides hold noise."""
+    out = set()
+    for name, seq in module.named_modules():
+        if not isinstance(seq, torch.nn.Sequential):
+            continue
+        layers = list(seq)
+        for i in range(len(layers) - 1):
+            a, b = layers[i], layers[i + 1]
+            if isinstance(a, (torch.nn.Conv2d, torch.nn.Conv3d)) and isinstance(b, torch.nn.GroupNorm) and b.num_groups == b.num_channels:
+                out.add(f"{name}.{i}.bias" if name else f"{i}.bias")
+    return out
+
+
 def _run(mode, fn):
     if mode == "bf16":
         with torch.autocast("cuda", dtype=torch.bfloat16):
@@ -439,3 +454,74 @@ def test_direct_model_full_size_64_vs_oracle_and_psnr():
     assert ((y32 - ref).abs().max() / ref.abs().max()).item() < F32_TOL
     p_ref, p32, p16 = O.psnr(ref, ct), O.psnr(y32, ct), O.psnr(y16, ct)
     assert abs(p32 - p_ref) < 0.1 and abs(p16 - p_ref) < 0.1, (p_ref, p32, p16)
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_cascade_refiners_vs_golden(golden, mode):
+    """Shared multi-scale X-ray encoder + stage-2 / stage-3 refiners (reduced sizes) chained as
+    ProgressiveCascadeModel.forward does, against the reference's outputs and gradients."""
+    from direct_regression.progressive_cascade.model_progressive import (MultiScaleXrayEncoder, Stage2Refiner128,
+                                                                         Stage3Refiner256)
+    g = golden("cascade_small")
+    enc = _load(MultiScaleXrayEncoder(img_size=64, in_channels=1, base_dim=32, num_views=2).eval(), g.group("enc_params"))
+    s2 = _load(Stage2Refiner128(volume_size=(32, 32, 32), voxel_dim=32, vit_depth=1, num_heads=1, xray_feature_dim=32).eval(),
+               g.group("s2_params"))
+    s3 = _load(Stage3Refiner256(volume_size=(64, 64, 64), voxel_dim=32, vit_depth=1, num_heads=1, xray_feature_dim=32,
+                                use_gradient_checkpointing=False).eval(), g.group("s3_params"))
+    xr = g.t("xrays").to(dev())
+    v16 = g.t("v16").to(dev()).requires_grad_(True)
+
+    def run():
+        f1, _, _ = enc(xr, stage=1)
+        f2, cond2, _ = enc(xr, stage=2)
+        v32 = s2(v16, f2, cond2)
+        f3, cond3, _ = enc(xr, stage=3)
+        return f1, f2, v32, s3(v32, f3, cond3)
+    f1, f2, v32, v64 = _run(mode, run)
+    tol, met = _tol(mode), _metric(mode)
+    g.check("", "feats1", f1, tol, 5, metric=met)
+    g.check("", "feats2", f2, tol, 5, metric=met)
+    g.check("", "v32", v32, tol, 5, metric=met)
+    g.check("", "v64", v64, tol, 5, metric=met)
+    ((v32.float() * g.t("w2").to(dev())).sum() + (v64.float() * g.t("w3").to(dev())).sum() + f1.float().sum() * 0.1).backward()
+    g.check("", "dv16", v16.grad, max(tol, 3e-3), 10, metric="l2")
+    for pre, m in (("enc", enc), ("s2", s2), ("s3", s3)):
+        for k, p in m.named_parameters():
+            if p.grad is None:
+                continue
+            if k in _zero_grad_biases(m):
+                continue   # conv bias ahead of a one-channel-per-group GroupNorm: exactly-zero gradient, rounding noise only
+            g.check(f"{pre}_pgrad", k, p.grad, max(tol, 3e-3), 10, metric="l2")    # ReLU / max-pool routing upstream: norm metric
+
+
+def test_drr_reprojection_loss_vs_golden(golden):
+    from direct_regression.progressive_cascade.loss_multiscale import DRRReprojectionLoss, compute_psnr
+    g = golden("drr")
+    vol = g.t("vol").to(dev()).requires_grad_(True)
+    rl = DRRReprojectionLoss(img_size=16)
+    loss = rl(vol, g.t("xr2").to(dev()))
+    assert abs(loss.item() - 0.516497) < 1e-5                    # SURVEY.md §9 known answer
+    loss.backward()
+    g.check("", "reproj_dvol", vol.grad, 1e-4)
+    g.check("", "reproj_ap", rl.generate_drr(vol.detach(), 0), 1e-5)
+    g.check("", "reproj_lat", rl.generate_drr(vol.detach(), 90), 1e-5)
+    assert compute_psnr(vol.detach(), vol.detach()) == float("inf")
+
+
+def test_multiscale_loss_stage1_matches_direct_loss():
+    from direct_regression.model_direct import DirectRegressionLoss
+    from direct_regression.progressive_cascade.loss_multiscale import MultiScaleLoss, compute_ssim_metric
+    from oracle import hvc_oracle as O
+    g = torch.Generator().manual_seed(9)
+    p = (torch.rand(2, 1, 16, 16, 16, generator=g) * 2 - 1)
+    t = (torch.rand(2, 1, 16, 16, 16, generator=g) * 2 - 1)
+    ref = O.direct_regression_loss(p, t)
+    a = MultiScaleLoss()(p.to(dev()), t.to(dev()), stage=1)
+    b = DirectRegressionLoss()(p.to(dev()), t.to(dev()))
+    for k in ("total_loss", "l1_loss", "ssim_loss"):
+        assert abs(a[k].item() - ref[k].item()) < 1e-5 and abs(b[k].item() - ref[k].item()) < 1e-5
+    assert abs(compute_ssim_metric(p.to(dev()), t.to(dev())) - (1 - ref["ssim_loss"].item())) < 1e-5
+    d = MultiScaleLoss()(p.to(dev()).requires_grad_(True), t.to(dev()), stage=3,
+                         input_xrays=torch.rand(2, 2, 1, 512, 512, generator=g).to(dev()))
+    assert set(d) == {"total_loss", "l1_loss", "ssim_loss", "vgg_loss", "tv_loss", "freq_loss", "drr_loss"}
+    d["total_loss"].backward()

@@ -165,3 +165,26 @@ def test_direct_regression_small(golden, mode):
     if mode == "train":
         for k, v in new_stats.items():
             g.check("train_stats_after", k, v, RTOL)
+
+
+def test_cascade_refiners_small(golden):
+    g = golden("cascade_small")
+    P = {}
+    for pre in ("enc", "s2", "s3"):
+        P.update({f"{pre}.{k}": v for k, v in _req(g.group(f"{pre}_params")).items()})
+    xr = g.t("xrays")
+    v16 = g.t("v16").requires_grad_(True)
+    f1, _, _ = O.multiscale_xray_encoder(xr, P, "enc.", 1)
+    f2, cond2, _ = O.multiscale_xray_encoder(xr, P, "enc.", 2)
+    v32 = O.stage2_refiner(v16, f2, cond2, P, "s2.", (32, 32, 32), 32, 1, 1)
+    f3, cond3, _ = O.multiscale_xray_encoder(xr, P, "enc.", 3)
+    v64 = O.stage3_refiner(v32, f3, cond3, P, "s3.", (64, 64, 64), 32, 1, 1)
+    g.check("", "feats1", f1, RTOL, 5)
+    g.check("", "feats2", f2, RTOL, 5)
+    g.check("", "v32", v32, RTOL, 5)
+    g.check("", "v64", v64, RTOL, 5)
+    ((v32 * g.t("w2")).sum() + (v64 * g.t("w3")).sum() + f1.sum() * 0.1).backward()
+    g.check("", "dv16", v16.grad, RTOL, 20)
+    for pre in ("enc", "s2", "s3"):
+        for k in g.keys(f"{pre}_pgrad"):
+            g.check(f"{pre}_pgrad", k, P[f"{pre}.{k}"].grad, RTOL, 50)
