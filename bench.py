@@ -200,15 +200,22 @@ def main():
                 a[0] += s.elapsed_time(e) * 1e-3
                 a[1] += work
                 a[2] += 1
-            # dominant kernel family by measured device time
+            # dominant kernel by measured device time (HIP events bracketing each launch on the launch stream)
             dom = max(agg, key=lambda k: agg[k][0])
             tsec, work, n = agg[dom]
+            traffic = None
+            try:   # HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/), same kernel & shape
+                pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+                traffic = pm.get(args.workload, {}).get(dom)
+            except (OSError, ValueError):
+                pass
             out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": work / tsec / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS,
-                               "unit": "TFLOP/s", "frac": work / tsec / 1e12 / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+                               "unit": "TFLOP/s", "frac": work / tsec / 1e12 / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic,
                                "launches": n, "avg_launch_ms": 1e3 * tsec / n,
                                "algorithmic_flops_per_launch": work / n}
             out["kernel_time_share"] = {k: {"ms_per_step": 1e3 * v[0] / args.steps, "tflops": v[1] / v[0] / 1e12 if v[0] else None,
-                                            "launches_per_step": v[2] / args.steps} for k, v in sorted(agg.items())}
+                                            "launches_per_step": v[2] / args.steps, "avg_launch_ms": 1e3 * v[0] / v[2]}
+                                        for k, v in sorted(agg.items())}
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

@@ -675,13 +675,14 @@ hipError_t launch_fwd(const AttnArgs& a, hipStream_t st) {
 
 template <typename T, int D, bool DROP, bool VEC>
 hipError_t launch_bwd(const AttnArgs& a, hipStream_t st) {
-    {
+    const int ph = a.phases ? a.phases : 7;
+    if (ph & 1) {
         const int64_t nthreads = (int64_t)a.B * a.H * a.Nq * (D / 8);
         hipLaunchKernelGGL((attn_delta_kernel<T, D>), dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, st, a);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
-    {
+    if (ph & 2) {
         const int nkb = (a.Nk + kQB - 1) / kQB;
         const size_t lds = dkv_lds_bytes<T, D>();
         auto k = attn_bwd_dkv_kernel<T, D, DROP, VEC>;
@@ -691,7 +692,7 @@ hipError_t launch_bwd(const AttnArgs& a, hipStream_t st) {
         e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
-    {
+    if (ph & 4) {
         const int nqb = (a.Nq + kQB - 1) / kQB;
         const size_t lds = fwd_lds_bytes<T, D>();
         auto k = attn_bwd_dq_kernel<T, D, DROP, VEC>;
@@ -700,6 +701,7 @@ hipError_t launch_bwd(const AttnArgs& a, hipStream_t st) {
         hipLaunchKernelGGL(k, dim3(nqb * a.B * a.H), dim3(256), lds, st, a);
         return hipGetLastError();
     }
+    return hipSuccess;
 }
 
 template <typename T, int D, bool DROP>

@@ -102,10 +102,12 @@ int hvc_attention_bwd(const void* q, const void* k, const void* v, const void* o
                       int B, int H, int Nq, int Nk, int D,
                       int64_t q_sb, int64_t q_sn, int64_t q_sh, int64_t k_sb, int64_t k_sn, int64_t k_sh,
                       int64_t v_sb, int64_t v_sn, int64_t v_sh, int64_t o_sb, int64_t o_sn, int64_t o_sh,
-                      float scale, float p_drop, uint64_t seed, int dtype, void* stream) {
+                      float scale, float p_drop, uint64_t seed, int phases, int dtype, void* stream) {
     hvc::AttnArgs a;
     int rc = fill_attn(a, q, k, v, B, H, Nq, Nk, D, q_sb, q_sn, q_sh, k_sb, k_sn, k_sh, v_sb, v_sn, v_sh, o_sb, o_sn, o_sh, scale, p_drop, seed, dtype);
     if (rc) return rc;
+    if (phases < 0 || phases > 7) return fail(HVC_E_BADARG, "attention_bwd: phases is a 3-bit mask");
+    a.phases = phases;
     if (!o || !dout || !lse || !delta_ws || !dq || !dk || !dv) return fail(HVC_E_BADARG, "attention_bwd: null operand");
     a.o = const_cast<void*>(o); a.dout = dout; a.lse = const_cast<float*>(lse); a.delta = delta_ws;
     a.dq = dq; a.dk = dk; a.dv = dv;

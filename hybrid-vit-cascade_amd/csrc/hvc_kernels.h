@@ -27,6 +27,7 @@ struct AttnArgs {
     uint32_t drop_thresh;   // 0 = no dropout; element dropped when its 16-bit lot < thresh
     float keep_scale;       // 1 / (1 - p)
     int vec;                // 16-byte vector access legal for every operand
+    int phases;             // bwd: bit 0 delta, bit 1 dK/dV kernel, bit 2 dQ kernel (0 = all)
     int is_bf16;
 };
 hipError_t attention_launch(const AttnArgs& a, bool bwd, hipStream_t st);

@@ -90,7 +90,7 @@ def attention_fwd(q, k, v, scale, p_drop=0.0, seed=0):
         raise ValueError("attention: q/k/v shape or dtype mismatch")
     o = torch.empty((B, Nq, H, D), dtype=q.dtype, device=q.device)
     lse = torch.empty((B, H, Nq), dtype=torch.float32, device=q.device)
-    with _Timed("attention_fwd", 4.0 * B * H * Nq * Nk * D):
+    with _Timed("attn_fwd_kernel", 4.0 * B * H * Nq * Nk * D):
       check(_lib.load().hvc_attention_fwd(
         q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse.data_ptr(), B, H, Nq, Nk, D,
         *_bnhd_strides(q), *_bnhd_strides(k), *_bnhd_strides(v), *_bnhd_strides(o),
@@ -119,12 +119,23 @@ def attention_bwd(q, k, v, o, dout, lse, scale, p_drop=0.0, seed=0, dq=None, dk=
         if g.shape != x.shape or any(gs != xs for gs, xs, sz in zip(g.stride(), x.stride(), x.shape) if sz > 1):
             raise ValueError(f"attention_bwd: {n} must have the shape and strides of its primal")
     delta = torch.empty((B, H, Nq), dtype=torch.float32, device=q.device)
-    with _Timed("attention_bwd", 10.0 * B * H * Nq * Nk * D):
-      check(_lib.load().hvc_attention_bwd(
-        q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), dout.data_ptr(), lse.data_ptr(),
-        delta.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), B, H, Nq, Nk, D,
-        *_bnhd_strides(q), *_bnhd_strides(k), *_bnhd_strides(v), *_bnhd_strides(o),
-        float(scale), float(p_drop), int(seed), _code(q.dtype), _stream()), "hvc_attention_bwd")
+    args = (q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), dout.data_ptr(), lse.data_ptr(),
+            delta.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), B, H, Nq, Nk, D,
+            *_bnhd_strides(q), *_bnhd_strides(k), *_bnhd_strides(v), *_bnhd_strides(o),
+            float(scale), float(p_drop), int(seed))
+    fn = _lib.load().hvc_attention_bwd
+    base = 2.0 * B * H * Nq * Nk * D          # flops of one Nq x Nk x D product
+    if PROFILE is None:
+        check(fn(*args, 0, _code(q.dtype), _stream()), "hvc_attention_bwd")
+    else:
+        # time the three launches separately; algorithmic flops: dK/dV kernel = S, dP, dV, dK (4 products),
+        # dQ kernel = dQ (its S / dP recompute is overhead of the split, not algorithmic work)
+        with _Timed("attn_delta_kernel", 0.0):
+            check(fn(*args, 1, _code(q.dtype), _stream()), "hvc_attention_bwd")
+        with _Timed("attn_bwd_dkv_kernel", 4 * base):
+            check(fn(*args, 2, _code(q.dtype), _stream()), "hvc_attention_bwd")
+        with _Timed("attn_bwd_dq_kernel", 1 * base):
+            check(fn(*args, 4, _code(q.dtype), _stream()), "hvc_attention_bwd")
     return dq, dk, dv
 
 
@@ -180,7 +191,7 @@ def gemm(a, b, *, a_kmajor=False, b_kmajor=False, alpha=1.0, bias=None, act=ACT_
         ws_n = lib.hvc_gemm_workspace(M, N, K)
         if ws_n > 0:
             ws = torch.empty((ws_n,), dtype=torch.float32, device=a.device)
-    with _Timed("gemm", 2.0 * M * N * K):
+    with _Timed("gemm_kernel", 2.0 * M * N * K):
       check(_lib.load().hvc_gemm(
         a.data_ptr(), b.data_ptr(), out.data_ptr(), M, N, K, _ld(a), _ld(b), _ld(out),
         int(a_kmajor), int(b_kmajor), float(alpha), _ptr(bias), int(act), _ptr(aux), _ptr(zsave),

@@ -62,7 +62,10 @@ int hvc_attention_fwd(const void* q, const void* k, const void* v, void* o, floa
                       float scale, float p_drop, uint64_t seed, int dtype, void* stream);
 
 /* Gradient of the above (autograd of the same reference lines).  delta_ws: [B*H][Nq] fp32 scratch.
- * dq/dk/dv use the strides of q/k/v respectively; dout uses the strides of o. */
+ * dq/dk/dv use the strides of q/k/v respectively; dout uses the strides of o.
+ * Three launches: delta = rowsum(dO * O) (bit 0 of `phases`), the dK/dV kernel (bit 1), the dQ kernel (bit 2);
+ * phases = 0 or 7 runs all of them, a sub-mask lets a caller time them separately (they must still be issued in
+ * that order on one stream). */
 int hvc_attention_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout,
                       const float* lse, float* delta_ws, void* dq, void* dk, void* dv,
                       int B, int H, int Nq, int Nk, int D,
@@ -70,7 +73,7 @@ int hvc_attention_bwd(const void* q, const void* k, const void* v, const void* o
                       int64_t k_sb, int64_t k_sn, int64_t k_sh,
                       int64_t v_sb, int64_t v_sn, int64_t v_sh,
                       int64_t o_sb, int64_t o_sn, int64_t o_sh,
-                      float scale, float p_drop, uint64_t seed, int dtype, void* stream);
+                      float scale, float p_drop, uint64_t seed, int phases, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * GEMM with fused epilogue:   z = dropout(act(alpha * A B^T + bias));  C = residual + gate_b * z
