@@ -525,3 +525,61 @@ def test_multiscale_loss_stage1_matches_direct_loss():
                          input_xrays=torch.rand(2, 2, 1, 512, 512, generator=g).to(dev()))
     assert set(d) == {"total_loss", "l1_loss", "ssim_loss", "vgg_loss", "tv_loss", "freq_loss", "drr_loss"}
     d["total_loss"].backward()
+
+
+def _ddp_gpu_worker(rank, world, port, out_dir):
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    sys.path.insert(0, os.path.join(root, "hybrid-vit-cascade_amd"))
+    from direct_regression import train_direct_4gpu as T
+    from direct_regression.model_direct import DirectCTRegression, DirectRegressionLoss
+    from hvc import synthetic
+    T.setup_ddp(rank, world, backend="gloo", port=str(port))       # both ranks share cuda:0; gloo moves the buckets
+    torch.cuda.set_device(0)
+    cfg = dict(volume_size=(16, 16, 16), xray_img_size=64, voxel_dim=64, vit_depth=1, num_heads=2, xray_feature_dim=32)
+    torch.manual_seed(0)
+    model = DirectCTRegression(**cfg).cuda(0).train()
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    crit = DirectRegressionLoss()
+    xr, ct = synthetic.batch(10 * rank, 2, cfg["volume_size"], cfg["xray_img_size"], device="cuda:0")
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        loss = crit(model(xr), ct)["total_loss"]
+    loss.backward()
+    local = {k: p.grad.clone() for k, p in model.named_parameters()}
+    model.zero_grad(set_to_none=True)
+    for m in model.modules():                     # undo the running-stat update of the probe pass
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.reset_running_stats()
+    ddp = T.wrap_ddp(model, [0])
+    opt = torch.optim.AdamW(ddp.parameters(), lr=1e-3, weight_decay=0.01)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        loss = crit(ddp(xr), ct)["total_loss"]
+    loss.backward()
+    reduced = {k: p.grad.clone() for k, p in model.named_parameters()}
+    T.train_step(ddp, crit, opt, None, xr, ct, gradient_clip=1.0)
+    torch.save({"local": {k: v.cpu() for k, v in local.items()}, "reduced": {k: v.cpu() for k, v in reduced.items()},
+                "params": {k: v.detach().cpu() for k, v in model.state_dict().items()}}, os.path.join(out_dir, f"rank{rank}.pt"))
+    T.cleanup_ddp()
+
+
+@pytest.mark.timeout(600)
+def test_ddp_two_ranks_on_the_hip_path(tmp_path):
+    """Two processes, both on cuda:0, DDP over gloo: checks that the HIP autograd Functions cooperate with DDP's
+    bucket hooks (gradient-as-bucket-view) -- reduced gradients are the mean of the ranks' local ones, parameters
+    stay identical after an optimizer step.  (The production launch is one rank per GPU over RCCL.)"""
+    import torch.multiprocessing as mp
+    world, port = 2, 29533
+    mp.spawn(_ddp_gpu_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = (torch.load(tmp_path / f"rank{r}.pt") for r in range(world))
+    for k in r0["reduced"]:
+        mean_local = (r0["local"][k] + r1["local"][k]) / 2
+        assert torch.allclose(r0["reduced"][k], mean_local, rtol=2e-3, atol=1e-6), k
+        assert torch.equal(r0["reduced"][k], r1["reduced"][k]), k
+    for k in r0["params"]:
+        if "running_" in k or "num_batches" in k:
+            continue   # BatchNorm statistics are per rank, as in the reference (no SyncBN); DDP re-broadcasts them at the next forward
+        assert torch.equal(r0["params"][k], r1["params"][k]), k
