@@ -266,12 +266,12 @@ int hvc_drr_bwd(const void* vol, const void* out, const void* dout, void* dvol, 
 }
 
 static int fill_geom(hvc::ConvGeom& g, int B, int C, int SD, int SH, int SW, int KD, int KH, int KW, int stride,
-                     int PD, int PH, int PW, int64_t Kp) {
+                     int PD, int PH, int PW, int OD, int64_t Kp) {
     if (B < 1 || C < 1 || SD < 1 || SH < 1 || SW < 1 || KD < 1 || KH < 1 || KW < 1 || stride < 1 || PD < 0 || PH < 0 || PW < 0)
         return fail(HVC_E_BADARG, "conv geometry: bad extent");
     g.B = B; g.C = C; g.SD = SD; g.SH = SH; g.SW = SW; g.KD = KD; g.KH = KH; g.KW = KW; g.stride = stride;
     g.PD = PD; g.PH = PH; g.PW = PW;
-    g.OD = (SD + 2 * PD - KD) / stride + 1; g.OH = (SH + 2 * PH - KH) / stride + 1; g.OW = (SW + 2 * PW - KW) / stride + 1;
+    g.OD = OD > 0 ? OD : (SD + 2 * PD - KD) / stride + 1; g.OH = (SH + 2 * PH - KH) / stride + 1; g.OW = (SW + 2 * PW - KW) / stride + 1;
     if (g.OD < 1 || g.OH < 1 || g.OW < 1) return fail(HVC_E_BADARG, "conv geometry: empty output");
     g.M = (int64_t)B * g.OD * g.OH * g.OW;
     g.Kp = Kp;
@@ -281,9 +281,9 @@ static int fill_geom(hvc::ConvGeom& g, int B, int C, int SD, int SH, int SW, int
 }
 
 int hvc_im2col(const void* src, void* col, int B, int C, int SD, int SH, int SW, int KD, int KH, int KW, int stride,
-               int PD, int PH, int PW, int64_t Kp, int dtype, void* stream) {
+               int PD, int PH, int PW, int OD, int64_t Kp, int dtype, void* stream) {
     hvc::ConvGeom g;
-    int rc = fill_geom(g, B, C, SD, SH, SW, KD, KH, KW, stride, PD, PH, PW, Kp);
+    int rc = fill_geom(g, B, C, SD, SH, SW, KD, KH, KW, stride, PD, PH, PW, OD, Kp);
     if (rc) return rc;
     if (!src || !col || !dtype_ok(dtype)) return fail(HVC_E_BADARG, "im2col: bad operand");
     if (C % 8 == 0 && !(aligned16(src) && aligned16(col))) return fail(HVC_E_BADARG, "im2col: operands must be 16-byte aligned");
@@ -291,9 +291,9 @@ int hvc_im2col(const void* src, void* col, int B, int C, int SD, int SH, int SW,
 }
 
 int hvc_col2im(const void* dcol, void* dsrc, int B, int C, int SD, int SH, int SW, int KD, int KH, int KW, int stride,
-               int PD, int PH, int PW, int64_t Kp, int dtype, void* stream) {
+               int PD, int PH, int PW, int OD, int64_t Kp, int dtype, void* stream) {
     hvc::ConvGeom g;
-    int rc = fill_geom(g, B, C, SD, SH, SW, KD, KH, KW, stride, PD, PH, PW, Kp);
+    int rc = fill_geom(g, B, C, SD, SH, SW, KD, KH, KW, stride, PD, PH, PW, OD, Kp);
     if (rc) return rc;
     if (!dcol || !dsrc || !dtype_ok(dtype)) return fail(HVC_E_BADARG, "col2im: bad operand");
     if (C % 8 == 0 && !(aligned16(dcol) && aligned16(dsrc))) return fail(HVC_E_BADARG, "col2im: operands must be 16-byte aligned");

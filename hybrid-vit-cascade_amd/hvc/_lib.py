@@ -34,8 +34,8 @@ SIGNATURES = {
     "hvc_colsum_workspace": (_i64, [_i, _i]),
     "hvc_colsum": (_i, [_p, _p, _p, _i, _i, _i, _p]),
     "hvc_cast": (_i, [_p, _p, _i64, _i, _i, _p]),
-    "hvc_im2col": (_i, [_p, _p] + [_i] * 12 + [_i64, _i, _p]),
-    "hvc_col2im": (_i, [_p, _p] + [_i] * 12 + [_i64, _i, _p]),
+    "hvc_im2col": (_i, [_p, _p] + [_i] * 13 + [_i64, _i, _p]),
+    "hvc_col2im": (_i, [_p, _p] + [_i] * 13 + [_i64, _i, _p]),
     "hvc_trilinear_fwd": (_i, [_p, _p] + [_i] * 8 + [_p]),
     "hvc_trilinear_bwd": (_i, [_p, _p] + [_i] * 8 + [_p]),
     "hvc_norm_workspace": (_i64, [_i, _i, _i, _i]),

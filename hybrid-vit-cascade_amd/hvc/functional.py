@@ -369,43 +369,116 @@ def conv_weight_2d(weight: torch.Tensor, dtype: torch.dtype, Kp: int) -> torch.T
     return w2
 
 
+CONV_SLAB_BYTES = 2 << 30     # patch matrices larger than this are built (and rebuilt in backward) slab by slab along D
+
+
+def _slab_plan(geom, esize, cap):
+    """Output-depth slab size so that one sample's slab patch matrix stays under `cap` bytes."""
+    per_od = geom.out[1] * geom.out[2] * geom.Kp * esize
+    return max(1, min(geom.out[0], cap // max(per_od, 1)))
+
+
+def _out_slab_geom(geom, od0, od1):
+    """Source window + slab geometry producing output depths [od0, od1) of one sample."""
+    s, p, K = geom.stride, geom.pad[0], geom.kernel[0]
+    lo_raw = od0 * s - p
+    lo, hi = max(0, lo_raw), min(geom.src[0], (od1 - 1) * s - p + K)
+    g = ops.ConvGeometry(1, geom.C, (hi - lo, geom.src[1], geom.src[2]), geom.kernel, s, (lo - lo_raw, geom.pad[1], geom.pad[2]),
+                         out_depth=od1 - od0)
+    return lo, hi, g
+
+
 class ConvFn(torch.autograd.Function):
     """Convolution on channels-last x (B, D, H, W, Cin) as im2col + MFMA GEMM (+ bias, + broadcast add of
-    `addvec` (N_tok, Cout), i.e. pos_embed, on the last stem layer).  Output (B, OD, OH, OW, Cout)."""
+    `addvec` (N_tok, Cout), i.e. pos_embed, on the last stem layer).  Output (B, OD, OH, OW, Cout).
+    Volumes whose patch matrix exceeds CONV_SLAB_BYTES run slab by slab along D (forward, dW and dx), the patch
+    matrix being rebuilt in the backward instead of saved."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, addvec, geom, cdt, out_dtype):
         xc = _as_cdt(x, cdt)
-        col = ops.im2col(xc, geom)
         w2d = conv_weight_2d(weight, cdt, geom.Kp)
+        cout = weight.shape[0]
+        esize = 2 if cdt == torch.bfloat16 else 4
+        slabbed = geom.M * geom.Kp * esize > CONV_SLAB_BYTES
         add = None
         if addvec is not None:
-            add = _f32(addvec).reshape(-1, weight.shape[0])
-        y = ops.gemm(col, w2d, bias=_f32(bias), residual=add, residual_rows=add.shape[0] if add is not None else 0,
-                     out_dtype=out_dtype)
-        ctx.save_for_backward(col, weight)
-        ctx.cfg = (geom, cdt, x.dtype, bias is not None, None if addvec is None else tuple(addvec.shape))
-        return y.view(geom.B, *geom.out, weight.shape[0])
+            if slabbed:
+                raise RuntimeError("ConvFn: the fused pos_embed add is only supported for un-slabbed (token-sized) outputs")
+            add = _f32(addvec).reshape(-1, cout)
+        if not slabbed:
+            col = ops.im2col(xc, geom)
+            y = ops.gemm(col, w2d, bias=_f32(bias), residual=add, residual_rows=add.shape[0] if add is not None else 0,
+                         out_dtype=out_dtype)
+            ctx.save_for_backward(col, weight)
+            y = y.view(geom.B, *geom.out, cout)
+        else:
+            y = torch.empty((geom.B, *geom.out, cout), dtype=out_dtype, device=x.device)
+            step = _slab_plan(geom, esize, CONV_SLAB_BYTES)
+            bf = _f32(bias)
+            for b in range(geom.B):
+                for od0 in range(0, geom.out[0], step):
+                    od1 = min(geom.out[0], od0 + step)
+                    lo, hi, g = _out_slab_geom(geom, od0, od1)
+                    col = ops.im2col(xc[b:b + 1, lo:hi], g)
+                    ops.gemm(col, w2d, bias=bf, out_dtype=out_dtype, out=y[b, od0:od1].view(g.M, cout))
+                    del col
+            ctx.save_for_backward(xc, weight)
+        ctx.cfg = (geom, cdt, x.dtype, bias is not None, None if addvec is None else tuple(addvec.shape), slabbed)
+        return y
 
     @staticmethod
     def backward(ctx, dy):
-        col, weight = ctx.saved_tensors
-        geom, cdt, xdt, has_bias, add_shape = ctx.cfg
+        saved, weight = ctx.saved_tensors
+        geom, cdt, xdt, has_bias, add_shape, slabbed = ctx.cfg
         cout = weight.shape[0]
-        dy2 = dy.reshape(geom.M, cout)
-        dyc = _as_cdt(dy2, cdt)
+        taps = geom.taps
+        dyc = _as_cdt(dy.reshape(geom.M, cout), cdt)
         db = ops.colsum(dyc) if has_bias and ctx.needs_input_grad[2] else None
-        dw = None
+        w2d = conv_weight_2d(weight, cdt, geom.Kp)
+        dw = dx = None
+        if not slabbed:
+            col = saved
+            if ctx.needs_input_grad[1]:
+                dw2d = ops.gemm(dyc, col, a_kmajor=True, b_kmajor=True, out_dtype=torch.float32)        # (Cout, Kp)
+            if ctx.needs_input_grad[0]:
+                dx = ops.col2im(ops.gemm(dyc, w2d, b_kmajor=True), geom)
+        else:
+            xc = saved
+            esize = 2 if cdt == torch.bfloat16 else 4
+            dy5 = dyc.view(geom.B, *geom.out, cout)
+            s, p, K = geom.stride, geom.pad[0], geom.kernel[0]
+            if ctx.needs_input_grad[1]:
+                dw2d = torch.zeros((cout, geom.Kp), dtype=torch.float32, device=dy.device)
+                step = _slab_plan(geom, esize, CONV_SLAB_BYTES)
+                for b in range(geom.B):
+                    for od0 in range(0, geom.out[0], step):
+                        od1 = min(geom.out[0], od0 + step)
+                        lo, hi, g = _out_slab_geom(geom, od0, od1)
+                        col = ops.im2col(xc[b:b + 1, lo:hi], g)
+                        dw2d += ops.gemm(dy5[b, od0:od1].view(g.M, cout), col, a_kmajor=True, b_kmajor=True, out_dtype=torch.float32)
+                        del col
+            if ctx.needs_input_grad[0]:
+                dx = torch.empty((geom.B, *geom.src, geom.C), dtype=cdt, device=dy.device)
+                # input slab [d0, d1) gathers from output depths [od_lo, od_hi); slab size chosen on the dcol matrix
+                step_in = max(1, _slab_plan(geom, esize, CONV_SLAB_BYTES) * s)
+                for b in range(geom.B):
+                    for d0 in range(0, geom.src[0], step_in):
+                        d1 = min(geom.src[0], d0 + step_in)
+                        od_lo = max(0, -((-(d0 + p - K + 1)) // s))
+                        od_hi = min(geom.out[0], (d1 - 1 + p) // s + 1)
+                        if od_hi <= od_lo:
+                            dx[b, d0:d1].zero_()
+                            continue
+                        g = ops.ConvGeometry(1, geom.C, (d1 - d0, geom.src[1], geom.src[2]), geom.kernel, s,
+                                             (p + d0 - od_lo * s, geom.pad[1], geom.pad[2]), out_depth=od_hi - od_lo)
+                        dcol = ops.gemm(dy5[b, od_lo:od_hi].view(g.M, cout), w2d, b_kmajor=True)
+                        dx[b, d0:d1] = ops.col2im(dcol, g)[0]
+                        del dcol
         if ctx.needs_input_grad[1]:
-            dw2d = ops.gemm(dyc, col, a_kmajor=True, b_kmajor=True, out_dtype=torch.float32)        # (Cout, Kp)
-            taps = geom.taps
             dw = dw2d[:, :taps * geom.C].reshape(cout, taps, geom.C).permute(0, 2, 1).reshape(weight.shape)
-        dx = None
-        if ctx.needs_input_grad[0]:
-            dcol = ops.gemm(dyc, conv_weight_2d(weight, cdt, geom.Kp), b_kmajor=True)                # (M, Kp)
-            dx = ops.col2im(dcol, geom)
-            if dx.dtype != xdt:
-                dx = dx.to(xdt)
+        if dx is not None and dx.dtype != xdt:
+            dx = dx.to(xdt)
         dadd = None
         if add_shape is not None and ctx.needs_input_grad[3]:
             dadd = dy.reshape(geom.B, -1, cout).float().sum(dim=0).reshape(add_shape)

@@ -327,17 +327,21 @@ def drr_bwd(vol, out, dout, axis, *, exp_mode, mu=0.3, out_scale=1.0, clamp_min=
 class ConvGeometry:
     """Geometry of one convolution on channels-last activations (2-D convs use D = KD = 1, PD = 0)."""
 
-    def __init__(self, B, C, src, kernel, stride, pad):
+    def __init__(self, B, C, src, kernel, stride, pad, out_depth=None):
+        """pad = (front D pad, H pad, W pad); out_depth overrides the symmetric-padding formula for depth slabs."""
         self.B, self.C = int(B), int(C)
         self.src, self.kernel, self.stride, self.pad = tuple(src), tuple(kernel), int(stride), tuple(pad)
         self.out = tuple((s + 2 * p - k) // self.stride + 1 for s, k, p in zip(self.src, self.kernel, self.pad))
+        self.out_depth = int(out_depth) if out_depth else 0
+        if self.out_depth:
+            self.out = (self.out_depth, self.out[1], self.out[2])
         self.taps = self.kernel[0] * self.kernel[1] * self.kernel[2]
         k = self.taps * self.C
         self.Kp = k if self.C % 8 == 0 else (k + 7) // 8 * 8
         self.M = self.B * self.out[0] * self.out[1] * self.out[2]
 
     def args(self):
-        return (self.B, self.C, *self.src, *self.kernel, self.stride, *self.pad, self.Kp)
+        return (self.B, self.C, *self.src, *self.kernel, self.stride, *self.pad, self.out_depth, self.Kp)
 
 
 def im2col(x, geom):

@@ -25,11 +25,8 @@ STAGE_BACKEND = {
     "xray_batchnorm_relu_pool": "hip",
     "xray_view_mean_gap": "aten",
     "ssim_l1_loss": "hip",
-    "cascade_glue_conv_gn_gelu_upsample": "hip (aten conv above the im2col memory cap)",
+    "cascade_glue_conv_gn_gelu_upsample": "hip (slab-wise im2col above 2 GiB)",
 }
-
-IM2COL_CAP_BYTES = 6 << 30     # patch matrices above this fall back to the ATen convolution (chunked im2col: next round)
-_warned_cap = False
 
 
 def _require_gpu(t):
@@ -47,7 +44,6 @@ def _channels_last(x):
 
 def conv_channels_last(h, layer, cdt, out_dtype=None, addvec=None):
     """nn.Conv3d / nn.Conv2d on a channels-last tensor (B, D, H, W, C) (2-D: D = 1) -> channels-last."""
-    global _warned_cap
     is3d = isinstance(layer, nn.Conv3d)
     ks = layer.kernel_size if is3d else (1, *layer.kernel_size)
     pad = layer.padding if is3d else (0, *layer.padding)
@@ -55,19 +51,6 @@ def conv_channels_last(h, layer, cdt, out_dtype=None, addvec=None):
         raise RuntimeError("HVC conv: anisotropic strides are not supported")
     geom = ops.ConvGeometry(h.shape[0], layer.in_channels, h.shape[1:4], ks, layer.stride[0], pad)
     out_dtype = out_dtype or cdt
-    if geom.M * geom.Kp * (2 if cdt == torch.bfloat16 else 4) > IM2COL_CAP_BYTES:
-        if not _warned_cap:
-            print(f"[hvc] conv {layer.in_channels}->{layer.out_channels} on {tuple(h.shape[1:4])}: patch matrix above "
-                  f"{IM2COL_CAP_BYTES >> 30} GiB, using the ATen convolution for this layer")
-            _warned_cap = True
-        with torch.autocast("cuda", enabled=False):
-            x = h.float().permute(0, 4, 1, 2, 3)
-            y = torch.nn.functional.conv3d(x, layer.weight if is3d else layer.weight.unsqueeze(2), layer.bias,
-                                           stride=layer.stride[0], padding=pad)
-        y = y.permute(0, 2, 3, 4, 1)
-        if addvec is not None:
-            y = y + addvec.reshape(1, *y.shape[1:])
-        return y.to(out_dtype).contiguous()
     return HF.ConvFn.apply(h, layer.weight, layer.bias, addvec, geom, cdt, out_dtype)
 
 

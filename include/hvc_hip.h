@@ -174,11 +174,14 @@ int hvc_drr_bwd(const void* vol, const void* out, const void* dout, void* dvol,
  *   dW = hvc_gemm(dy, col, a_kmajor, b_kmajor)              (split-K)
  * col is [B*OD*OH*OW][Kp], column index = tap*C + c, tap = (kd*KH + kh)*KW + kw; Kp = taps*C when
  * C % 8 == 0, else taps*C rounded up to a multiple of 8 (zero filled).  O = (S + 2P - K)/stride + 1.
+ * Depth slabs: a large volume is convolved in slabs along D; for a slab the caller passes the slab extent as SD,
+ * the FRONT padding as PD (the back padding is implied: rows beyond SD read as zero) and the slab's output
+ * depth as OD (> 0; 0 = derive from the symmetric formula).
  * ---------------------------------------------------------------------------------------------- */
 int hvc_im2col(const void* src, void* col, int B, int C, int SD, int SH, int SW, int KD, int KH, int KW,
-               int stride, int PD, int PH, int PW, int64_t Kp, int dtype, void* stream);
+               int stride, int PD, int PH, int PW, int OD, int64_t Kp, int dtype, void* stream);
 int hvc_col2im(const void* dcol, void* dsrc, int B, int C, int SD, int SH, int SW, int KD, int KH, int KW,
-               int stride, int PD, int PH, int PW, int64_t Kp, int dtype, void* stream);
+               int stride, int PD, int PH, int PW, int OD, int64_t Kp, int dtype, void* stream);
 
 /* Trilinear resize of single-channel fp32 volumes [B][d][h][w] -> [B][D][H][W] and its adjoint:
  * align_corners=1 for F.interpolate at models/hybrid_vit_backbone.py:272; align_corners=0 for the cascade's

@@ -583,3 +583,44 @@ def test_ddp_two_ranks_on_the_hip_path(tmp_path):
         if "running_" in k or "num_batches" in k:
             continue   # BatchNorm statistics are per rank, as in the reference (no SyncBN); DDP re-broadcasts them at the next forward
         assert torch.equal(r0["params"][k], r1["params"][k]), k
+
+
+@pytest.mark.parametrize("cfg", [(3, 2, 16, 24, 3, 1, 1, (10, 9, 8)), (3, 1, 8, 16, 3, 2, 1, (13, 8, 8)), (3, 2, 1, 8, 3, 2, 1, (12, 6, 6)),
+                                 (3, 1, 32, 8, 1, 1, 0, (9, 4, 4))])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_conv_slabbed_equals_whole_and_oracle(cfg, dtype):
+    """Convolution run slab by slab along D (large-volume path) == the single-shot path == F.conv3d of the oracle."""
+    import torch.nn.functional as F
+    from hvc import functional as HF
+    from hvc import ops
+    dims, B, Cin, Cout, k, stride, pad, sp = cfg
+    g = torch.Generator().manual_seed(Cin * 7 + Cout)
+    x = torch.randn(B, Cin, *sp, generator=g)
+    w = torch.randn(Cout, Cin, k, k, k, generator=g) / (Cin * k ** 3) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    xr, wr, br = (t.to(dtype).double().requires_grad_(True) for t in (x, w, b))
+    y_ref = F.conv3d(xr, wr, br, stride=stride, padding=pad)
+    dy = torch.randn(y_ref.shape, generator=g)
+    y_ref.backward(dy.to(dtype).double())
+    geom = ops.ConvGeometry(B, Cin, sp, (k,) * 3, stride, (pad,) * 3)
+    results = []
+    for cap in (HF.CONV_SLAB_BYTES, 4096):
+        old = HF.CONV_SLAB_BYTES
+        HF.CONV_SLAB_BYTES = cap
+        try:
+            xd = x.to(dev()).to(dtype).permute(0, 2, 3, 4, 1).contiguous().requires_grad_(True)
+            wd = w.to(dev()).to(dtype).float().requires_grad_(True)
+            bd = b.to(dev()).to(dtype).float().requires_grad_(True)
+            y = HF.ConvFn.apply(xd, wd, bd, None, geom, dtype, dtype)
+            (y.float() * dy.to(dev()).to(dtype).permute(0, 2, 3, 4, 1).float()).sum().backward()
+            results.append((y.detach().permute(0, 4, 1, 2, 3).float().cpu(), xd.grad.permute(0, 4, 1, 2, 3).float().cpu(),
+                            wd.grad.cpu(), bd.grad.cpu()))
+        finally:
+            HF.CONV_SLAB_BYTES = old
+    tol = 1e-4 if dtype == torch.float32 else 2e-2
+    refs = (y_ref.detach(), xr.grad, wr.grad, br.grad)
+    for got in results:
+        for a, r in zip(got, refs):
+            assert ((a.double() - r).abs().max() / (r.abs().max() + 1e-12)).item() < tol
+    for a, c in zip(*results):       # slab-wise vs single shot: same products, only the dW summation order differs
+        assert torch.allclose(a, c, rtol=1e-3 if dtype == torch.float32 else 2e-2, atol=1e-4 if dtype == torch.float32 else 2e-2)
