@@ -490,7 +490,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a) 
     constexpr int TILE = kKT * D;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16* lds = reinterpret_cast<bf16*>(smem);                       // [buf][Q|dO][NS][TILE]
-    float* stat = reinterpret_cast<float*>(lds + 4 * NS * TILE);     // [buf][lse2|delta|rowkey][kKT]
+    float* stat = reinterpret_cast<float*>(lds + 4 * NS * TILE);     // [buf][lse2|delta][kKT]
+    // [buf][64 q][128 keys] 16-bit dropout lots of the current q-tile x this workgroup's keys, generated cooperatively
+    // (one hash per 4 keys, as in the forward) so that the per-element cost is a 2-byte LDS read + compare + selects.
+    uint16_t* lots = reinterpret_cast<uint16_t*>(stat + 2 * 2 * kKT);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
 
@@ -519,21 +522,34 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a) 
     auto Dt = [&](int buf) { return lds + (buf * 2 + 1) * NS * TILE; };
     const int nt = (a.Nq + kKT - 1) / kKT;
     float st_l = 0.f, st_d = 0.f;
-    uint32_t st_k = 0u;
     auto issue_stat = [&](int t) {
         if (tid < kKT) {
             int q = t * kKT + tid;
             const bool ok = q < a.Nq;
             st_l = ok ? a.lse[(int64_t)bh * a.Nq + q] * kLog2e : INFINITY;
             st_d = ok ? a.delta[(int64_t)bh * a.Nq + q] * (DROP ? 1.f / a.keep_scale : 1.f) : 0.f;
-            if constexpr (DROP) st_k = drop_rowkey(a, bh, ok ? q : a.Nq - 1);
         }
     };
     auto commit_stat = [&](int buf) {
         if (tid < kKT) {
-            stat[(buf * 3 + 0) * kKT + tid] = st_l;
-            stat[(buf * 3 + 1) * kKT + tid] = st_d;
-            if constexpr (DROP) reinterpret_cast<uint32_t*>(stat)[(buf * 3 + 2) * kKT + tid] = st_k;
+            stat[(buf * 2 + 0) * kKT + tid] = st_l;
+            stat[(buf * 2 + 1) * kKT + tid] = st_d;
+        }
+    };
+    // thread -> (q row tid>>2 of the tile, 32-key quarter tid&3 of the workgroup's 128 keys): 8 hashes, 32 lots
+    auto gen_lots = [&](int t, int buf) {
+        if constexpr (DROP) {
+            const int ql = tid >> 2, part = tid & 3;
+            const int q = min(t * kKT + ql, a.Nq - 1);
+            const uint32_t rk = drop_rowkey(a, bh, q);
+            const int key0 = kb * kQB + 32 * part;
+            uint32_t* dst = reinterpret_cast<uint32_t*>(lots + ((size_t)buf * kKT + ql) * kQB + 32 * part);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const uint32_t m = drop_mix(rk, (uint32_t)((key0 + 4 * u) >> 2) * kKeyMul);
+                dst[2 * u] = drop_lots(m, kLotMulA);
+                dst[2 * u + 1] = drop_lots(m, kLotMulB);
+            }
         }
     };
     ql.issue(qp, a.q_sn, 0, a.Nq, tid);
@@ -542,6 +558,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a) 
     ql.commit(Qt(0), tid);
     dl.commit(Dt(0), tid);
     commit_stat(0);
+    gen_lots(0, 0);
     __syncthreads();
 
     const float sl2 = a.scale * kLog2e;
@@ -550,9 +567,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a) 
     for (int dt = 0; dt < D / 32; ++dt)
 #pragma unroll
         for (int i = 0; i < 16; ++i) { dk[dt][i] = 0.f; dv[dt][i] = 0.f; }
-    const uint32_t keyterm = (uint32_t)((kvalid ? krow : 0) >> 2) * kKeyMul;
-    const uint32_t lotmul = (krow & 2) ? kLotMulB : kLotMulA;
-    const int lot_shift = 16 * (krow & 1);
+    const int kcol = wave * 32 + r;          // this lane's key column in the lots tile
 
     for (int t = 0; t < nt; ++t) {
         const int buf = t & 1;
@@ -585,11 +600,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a) 
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int ro = 32 * qt + 8 * g + 4 * h;
-                const f32x4 l4 = *reinterpret_cast<const f32x4*>(stat + (buf * 3 + 0) * kKT + ro);
-                const f32x4 d4 = *reinterpret_cast<const f32x4*>(stat + (buf * 3 + 1) * kKT + ro);
-                typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
-                u32x4 k4 = {0u, 0u, 0u, 0u};
-                if constexpr (DROP) k4 = *reinterpret_cast<const u32x4*>(reinterpret_cast<const uint32_t*>(stat) + (buf * 3 + 2) * kKT + ro);
+                const f32x4 l4 = *reinterpret_cast<const f32x4*>(stat + (buf * 2 + 0) * kKT + ro);
+                const f32x4 d4 = *reinterpret_cast<const f32x4*>(stat + (buf * 2 + 1) * kKT + ro);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int i = 4 * g + j;
@@ -597,7 +609,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a) 
                     float dpv = dp[i];
                     float pdv = p;
                     if constexpr (DROP) {   // 1/(1-p) is folded into delta (pre-divided) and the epilogue scales
-                        const bool keep = ((drop_lots(drop_mix(k4[j], keyterm), lotmul) >> lot_shift) & 0xffffu) >= a.drop_thresh;
+                        const bool keep = lots[((size_t)buf * kKT + ro + j) * kQB + kcol] >= a.drop_thresh;
                         pdv = keep ? p : 0.f;
                         dpv = keep ? dpv : 0.f;
                     }
@@ -633,6 +645,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a) 
             ql.commit(Qt(buf ^ 1), tid);
             dl.commit(Dt(buf ^ 1), tid);
             commit_stat(buf ^ 1);
+            gen_lots(t + 1, buf ^ 1);
         }
         __syncthreads();
     }
@@ -653,7 +666,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a) 
 template <typename T, int D>
 size_t fwd_lds_bytes() { return (size_t)2 * 2 * NSplit<T>::value * kKT * D * sizeof(bf16); }
 template <typename T, int D>
-size_t dkv_lds_bytes() { return fwd_lds_bytes<T, D>() + 2 * 3 * kKT * sizeof(float); }
+size_t dkv_lds_bytes(bool drop) { return fwd_lds_bytes<T, D>() + 2 * 2 * kKT * sizeof(float) + (drop ? 2 * kKT * kQB * sizeof(uint16_t) : 0); }
 
 template <typename K>
 hipError_t set_lds(K kernel, size_t bytes) {
@@ -684,7 +697,7 @@ hipError_t launch_bwd(const AttnArgs& a, hipStream_t st) {
     }
     if (ph & 2) {
         const int nkb = (a.Nk + kQB - 1) / kQB;
-        const size_t lds = dkv_lds_bytes<T, D>();
+        const size_t lds = dkv_lds_bytes<T, D>(DROP);
         auto k = attn_bwd_dkv_kernel<T, D, DROP, VEC>;
         hipError_t e = set_lds(k, lds);
         if (e != hipSuccess) return e;

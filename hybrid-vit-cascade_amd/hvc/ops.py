@@ -13,9 +13,12 @@ from ._lib import HVC_BF16, HVC_F32, check
 
 _DT = {torch.float32: HVC_F32, torch.bfloat16: HVC_BF16}
 
-# Optional per-call timing (bench.py): when PROFILE is a list, every wrapper brackets its launches
-# with HIP events recorded on the launch stream and appends (name, algorithmic_work, start, end).
+# Optional per-call timing (bench.py): when PROFILE is a list, the wrappers bracket their launches
+# with HIP events recorded on the launch stream and append (name, algorithmic_work, start, end).
+# PROFILE_ONLY (a set of names, or None = all) restricts the bracketing, so the timed region of the
+# benchmark can carry events for the dominant kernels only (a few dozen per step).
 PROFILE = None
+PROFILE_ONLY = None
 
 
 class _Timed:
@@ -25,7 +28,7 @@ class _Timed:
         self.name, self.work, self.start = name, work, None
 
     def __enter__(self):
-        if PROFILE is not None:
+        if PROFILE is not None and (PROFILE_ONLY is None or self.name in PROFILE_ONLY):
             self.start = torch.cuda.Event(enable_timing=True)
             self.start.record()
         return self
@@ -125,7 +128,7 @@ def attention_bwd(q, k, v, o, dout, lse, scale, p_drop=0.0, seed=0, dq=None, dk=
             float(scale), float(p_drop), int(seed))
     fn = _lib.load().hvc_attention_bwd
     base = 2.0 * B * H * Nq * Nk * D          # flops of one Nq x Nk x D product
-    if PROFILE is None:
+    if PROFILE is None or (PROFILE_ONLY is not None and "attn_bwd_dkv_kernel" not in PROFILE_ONLY):
         check(fn(*args, 0, _code(q.dtype), _stream()), "hvc_attention_bwd")
     else:
         # time the three launches separately; algorithmic flops: dK/dV kernel = S, dP, dV, dK (4 products),
