@@ -309,8 +309,8 @@ hipError_t launch(const GemmArgs& g_in, hipStream_t st) {
     g.splitk = 1;
     const bool plain = !g.bias && g.act == kActNone && !g.aux && !g.zsave && !g.gate && !g.residual && !g.drop_thresh;
     if (plain && g.workspace && tiles <= 128 && nkt >= 8) {
-        int want = (768 + tiles - 1) / tiles;
-        if (want > nkt / 2) want = nkt / 2;
+        int want = (512 + tiles - 1) / tiles;
+        if (want > nkt / 4) want = nkt / 4;          // >= 4 k-tiles per slice: slab traffic stays below the operand traffic
         const int64_t fit = g.workspace_floats / ((int64_t)g.M * g.N);
         if (want > fit) want = (int)fit;
         if (want >= 2) g.splitk = want;
@@ -335,9 +335,9 @@ hipError_t launch_layout(const GemmArgs& g, hipStream_t st) {
 int64_t gemm_workspace_floats(int M, int N, int K) {
     const int tiles = ((M + kBM - 1) / kBM) * ((N + kBN - 1) / kBN);
     if (tiles > 128 || K < 8 * 32) return 0;
-    int want = (768 + tiles - 1) / tiles;
+    int want = (512 + tiles - 1) / tiles;
     const int nkt = (K + 31) / 32;
-    if (want > nkt / 2) want = nkt / 2;
+    if (want > nkt / 4) want = nkt / 4;
     return want >= 2 ? (int64_t)want * M * N : 0;
 }
 

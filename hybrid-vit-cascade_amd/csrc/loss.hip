@@ -81,15 +81,24 @@ __global__ __launch_bounds__(256) void ssim_point_kernel(const float* __restrict
     }
 }
 
-// out[0] = total, out[1] = l1, out[2] = ssim loss
-__global__ void loss_finish_kernel(const float* __restrict__ partial, int nblk, float* out, double inv_n, float l1_w, float ssim_w) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// out[0] = total, out[1] = l1, out[2] = ssim loss.  One 256-thread block, fixed summation order (deterministic).
+__global__ __launch_bounds__(256) void loss_finish_kernel(const float* __restrict__ partial, int nblk, float* out, double inv_n, float l1_w, float ssim_w) {
+    __shared__ double red[2][256];
     double s = 0.0, l = 0.0;
-    for (int i = 0; i < nblk; ++i) { s += partial[2 * i]; l += partial[2 * i + 1]; }
-    const float l1 = (float)(l * inv_n), ss = (float)(1.0 - s * inv_n);
-    out[0] = l1_w * l1 + ssim_w * ss;
-    out[1] = l1;
-    out[2] = ss;
+    for (int i = threadIdx.x; i < nblk; i += 256) { s += partial[2 * i]; l += partial[2 * i + 1]; }
+    red[0][threadIdx.x] = s;
+    red[1][threadIdx.x] = l;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (threadIdx.x < off) { red[0][threadIdx.x] += red[0][threadIdx.x + off]; red[1][threadIdx.x] += red[1][threadIdx.x + off]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float l1 = (float)(red[1][0] * inv_n), ss = (float)(1.0 - red[0][0] * inv_n);
+        out[0] = l1_w * l1 + ssim_w * ss;
+        out[1] = l1;
+        out[2] = ss;
+    }
 }
 
 // last backward axis pass (along D) fused with the combination into dpred
@@ -139,7 +148,7 @@ hipError_t ssim_l1_fwd_launch(const LossArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(ssim_pass_w_kernel, dim3(grid_for(nvox)), dim3(256), 0, st, a.pred, a.target, A, nvox / a.W, a.W, R);
     hipLaunchKernelGGL(box_axis_kernel, dim3(grid_for(5 * nvox)), dim3(256), 0, st, A, Bw, 5 * nvox, a.H, (int64_t)a.W, R);
     hipLaunchKernelGGL(ssim_point_kernel, dim3(nblk), dim3(256), 0, st, Bw, a.pred, a.target, a.gmaps, partial, nvox, a.D, HW, R, inv_win);
-    hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(64), 0, st, partial, nblk, a.out, 1.0 / (double)nvox, a.l1_w, a.ssim_w);
+    hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(256), 0, st, partial, nblk, a.out, 1.0 / (double)nvox, a.l1_w, a.ssim_w);
     return hipGetLastError();
 }
 

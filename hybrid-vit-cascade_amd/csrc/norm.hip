@@ -93,32 +93,60 @@ __global__ __launch_bounds__(256) void chan_stats_kernel(const T* __restrict__ x
     for (int i = threadIdx.x; i < 2 * C; i += 256) dst[i] = out[i];
 }
 
-// GroupNorm finish: stats[b][g] = (mean, rstd) over P * cg elements
-__global__ __launch_bounds__(256) void gn_finish_kernel(const float* __restrict__ partial, float* __restrict__ stats,
-                                                         int B, int P, int C, int G, int nchunk, float eps) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= B * G) return;
-    const int b = i / G, g = i % G, cg = C / G;
-    double s = 0.0, ss = 0.0;
-    for (int ch = 0; ch < nchunk; ++ch) {
-        const float* p = partial + ((int64_t)b * nchunk + ch) * 2 * C;
-        for (int c = g * cg; c < (g + 1) * cg; ++c) { s += p[c]; ss += p[C + c]; }
-    }
-    const double n = (double)P * cg, mean = s / n;
-    double var = ss / n - mean * mean;
-    if (var < 0) var = 0;
-    stats[2 * i] = (float)mean;
-    stats[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
+// Sums partial[r][which][c] over r in [r0, r1) for 32 consecutive channels per block (256 threads = 32 channels x 8
+// row groups, fp64, fixed order).  Result valid in the threads with (tid >> 5) == 0.
+__device__ __forceinline__ void chan_sums2(const float* __restrict__ partial, int r0, int r1, int C, int c, bool valid,
+                                           double (*red)[8][32], double& s0, double& s1) {
+    const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    double a = 0.0, b = 0.0;
+    if (valid)
+        for (int r = r0 + rg; r < r1; r += 8) { a += partial[(int64_t)r * 2 * C + c]; b += partial[(int64_t)r * 2 * C + C + c]; }
+    red[0][rg][cl] = a;
+    red[1][rg][cl] = b;
+    __syncthreads();
+    s0 = 0.0; s1 = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { s0 += red[0][k][cl]; s1 += red[1][k][cl]; }
 }
 
-// BatchNorm finish (train): per channel over all samples; also updates the running statistics.
+// GroupNorm finish: stats[b][g] = (mean, rstd) over P * cg elements.  grid = B * G blocks of 256 threads.
+__global__ __launch_bounds__(256) void gn_finish_kernel(const float* __restrict__ partial, float* __restrict__ stats,
+                                                         int B, int P, int C, int G, int nchunk, float eps) {
+    __shared__ double red[2][256];
+    const int i = blockIdx.x, b = i / G, g = i % G, cg = C / G;
+    double s = 0.0, ss = 0.0;
+    for (int j = threadIdx.x; j < nchunk * cg; j += 256) {
+        const int ch = j / cg, c = g * cg + j % cg;
+        const float* p = partial + ((int64_t)b * nchunk + ch) * 2 * C;
+        s += p[c];
+        ss += p[C + c];
+    }
+    red[0][threadIdx.x] = s;
+    red[1][threadIdx.x] = ss;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (threadIdx.x < off) { red[0][threadIdx.x] += red[0][threadIdx.x + off]; red[1][threadIdx.x] += red[1][threadIdx.x + off]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double n = (double)P * cg, mean = red[0][0] / n;
+        double var = red[1][0] / n - mean * mean;
+        if (var < 0) var = 0;
+        stats[2 * i] = (float)mean;
+        stats[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+}
+
+// BatchNorm finish (train): per channel over all samples; also updates the running statistics.  grid = ceil(C/32).
 __global__ __launch_bounds__(256) void bn_finish_kernel(const float* __restrict__ partial, float* __restrict__ stats /*[C][2]*/,
                                                          float* running_mean, float* running_var, int B, int P, int C, int nchunk,
                                                          float eps, float momentum) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
-    double s = 0.0, ss = 0.0;
-    for (int i = 0; i < B * nchunk; ++i) { s += partial[(int64_t)i * 2 * C + c]; ss += partial[(int64_t)i * 2 * C + C + c]; }
+    __shared__ double red[2][8][32];
+    const int c = 32 * blockIdx.x + (threadIdx.x & 31);
+    const bool valid = c < C;
+    double s, ss;
+    chan_sums2(partial, 0, B * nchunk, C, c, valid, red, s, ss);
+    if (!valid || (threadIdx.x >> 5) != 0) return;
     const double n = (double)B * P, mean = s / n;
     double var = ss / n - mean * mean;
     if (var < 0) var = 0;
@@ -201,25 +229,37 @@ __global__ __launch_bounds__(256) void gn_silu_bwd_reduce_kernel(const T* __rest
     for (int i = threadIdx.x; i < 2 * C; i += 256) dst[i] = out[i];
 }
 
-// finish: dgamma, dbeta [C]; gsum[b][g] = (sum_c gamma ds, sum_c gamma ds xhat)
+// finish: blocks [0, ceil(C/32)) -> dgamma, dbeta [C];  blocks ceil(C/32) + (b*G + g) -> gsum[b][g] = (sum_c gamma ds, sum_c gamma ds xhat)
 __global__ __launch_bounds__(256) void gn_bwd_finish_kernel(const float* __restrict__ partial, const float* __restrict__ gamma,
                                                              float* dgamma, float* dbeta, float* gsum, int B, int C, int G, int nchunk) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < C) {
-        double s = 0.0, sx = 0.0;
-        for (int k = 0; k < B * nchunk; ++k) { s += partial[(int64_t)k * 2 * C + i]; sx += partial[(int64_t)k * 2 * C + C + i]; }
-        dbeta[i] = (float)s;
-        dgamma[i] = (float)sx;
-    } else if (i < C + B * G) {
-        const int j = i - C, b = j / G, g = j % G, cg = C / G;
-        double s1 = 0.0, s2 = 0.0;
-        for (int ch = 0; ch < nchunk; ++ch) {
-            const float* p = partial + ((int64_t)b * nchunk + ch) * 2 * C;
-            for (int c = g * cg; c < (g + 1) * cg; ++c) { s1 += (double)gamma[c] * p[c]; s2 += (double)gamma[c] * p[C + c]; }
-        }
-        gsum[2 * j] = (float)s1;
-        gsum[2 * j + 1] = (float)s2;
+    __shared__ double red[2][8][32];
+    const int ncb = (C + 31) / 32;
+    if ((int)blockIdx.x < ncb) {
+        const int c = 32 * blockIdx.x + (threadIdx.x & 31);
+        const bool valid = c < C;
+        double s, sx;
+        chan_sums2(partial, 0, B * nchunk, C, c, valid, red, s, sx);
+        if (valid && (threadIdx.x >> 5) == 0) { dbeta[c] = (float)s; dgamma[c] = (float)sx; }
+        return;
     }
+    double* flat0 = &red[0][0][0];
+    double* flat1 = &red[1][0][0];
+    const int j = blockIdx.x - ncb, b = j / G, g = j % G, cg = C / G;
+    double s1 = 0.0, s2 = 0.0;
+    for (int k = threadIdx.x; k < nchunk * cg; k += 256) {
+        const int ch = k / cg, c = g * cg + k % cg;
+        const float* p = partial + ((int64_t)b * nchunk + ch) * 2 * C;
+        s1 += (double)gamma[c] * p[c];
+        s2 += (double)gamma[c] * p[C + c];
+    }
+    flat0[threadIdx.x] = s1;
+    flat1[threadIdx.x] = s2;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (threadIdx.x < off) { flat0[threadIdx.x] += flat0[threadIdx.x + off]; flat1[threadIdx.x] += flat1[threadIdx.x + off]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { gsum[2 * j] = (float)flat0[0]; gsum[2 * j + 1] = (float)flat1[0]; }
 }
 
 template <typename T>
@@ -356,13 +396,15 @@ __global__ __launch_bounds__(256) void bn_relu_pool_bwd_reduce_kernel(const T* _
     for (int i = threadIdx.x; i < 2 * C; i += 256) dst[i] = out[i];
 }
 
-// finish: dgamma, dbeta and the per-channel means (c1, c2) of ds and ds * xhat
+// finish: dgamma, dbeta and the per-channel means (c1, c2) of ds and ds * xhat.  grid = ceil(C/32).
 __global__ __launch_bounds__(256) void bn_bwd_finish_kernel(const float* __restrict__ partial, float* dgamma, float* dbeta, float* cmean,
                                                              int N, int P, int C, int nchunk) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
-    double s = 0.0, sx = 0.0;
-    for (int k = 0; k < N * nchunk; ++k) { s += partial[(int64_t)k * 2 * C + c]; sx += partial[(int64_t)k * 2 * C + C + c]; }
+    __shared__ double red[2][8][32];
+    const int c = 32 * blockIdx.x + (threadIdx.x & 31);
+    const bool valid = c < C;
+    double s, sx;
+    chan_sums2(partial, 0, N * nchunk, C, c, valid, red, s, sx);
+    if (!valid || (threadIdx.x >> 5) != 0) return;
     dbeta[c] = (float)s;
     dgamma[c] = (float)sx;
     const double n = (double)N * P;
@@ -425,7 +467,7 @@ hipError_t groupnorm_silu_fwd_launch(const NormArgs& a, hipStream_t st) {
     if (a.C % 8 || a.C > kMaxC || 256 % (a.C / 8) || a.C % a.G) return hipErrorInvalidValue;
     const int nch = norm_chunks(a.P);
     HVC_DISPATCH_T(a.is_bf16, hipLaunchKernelGGL(chan_stats_kernel<T>, dim3(nch, a.B), dim3(256), 0, st, (const T*)a.x, a.partial, a.P, a.C, nch));
-    hipLaunchKernelGGL(gn_finish_kernel, dim3((a.B * a.G + 255) / 256), dim3(256), 0, st, a.partial, a.stats, a.B, a.P, a.C, a.G, nch, a.eps);
+    hipLaunchKernelGGL(gn_finish_kernel, dim3(a.B * a.G), dim3(256), 0, st, a.partial, a.stats, a.B, a.P, a.C, a.G, nch, a.eps);
     HVC_DISPATCH_T(a.is_bf16, hipLaunchKernelGGL(gn_silu_fwd_kernel<T>, dim3(grid_for((int64_t)a.B * a.P * a.C / 8)), dim3(256), 0, st,
                                                  (const T*)a.x, (T*)a.y, a.stats, a.gamma, a.beta, a.B, a.P, a.C, a.G, a.act));
     return hipGetLastError();
@@ -436,7 +478,7 @@ hipError_t groupnorm_silu_bwd_launch(const NormArgs& a, hipStream_t st) {
     const int nch = norm_chunks(a.P);
     HVC_DISPATCH_T(a.is_bf16, hipLaunchKernelGGL(gn_silu_bwd_reduce_kernel<T>, dim3(nch, a.B), dim3(256), 0, st, (const T*)a.x, (const T*)a.dy,
                                                  a.stats, a.gamma, a.beta, a.partial, a.P, a.C, a.G, nch, a.act));
-    hipLaunchKernelGGL(gn_bwd_finish_kernel, dim3((a.C + a.B * a.G + 255) / 256), dim3(256), 0, st, a.partial, a.gamma, a.dgamma, a.dbeta,
+    hipLaunchKernelGGL(gn_bwd_finish_kernel, dim3((a.C + 31) / 32 + a.B * a.G), dim3(256), 0, st, a.partial, a.gamma, a.dgamma, a.dbeta,
                        a.gsum, a.B, a.C, a.G, nch);
     HVC_DISPATCH_T(a.is_bf16, hipLaunchKernelGGL(gn_silu_bwd_apply_kernel<T>, dim3(grid_for((int64_t)a.B * a.P * a.C / 8)), dim3(256), 0, st,
                                                  (const T*)a.x, (const T*)a.dy, (T*)a.dx, a.stats, a.gsum, a.gamma, a.beta, a.B, a.P, a.C, a.G, a.act));
@@ -449,7 +491,7 @@ hipError_t bn_relu_pool_fwd_launch(const NormArgs& a, const PoolGeom& pg, hipStr
     const int nch = norm_chunks(P);
     if (a.training) {
         HVC_DISPATCH_T(a.is_bf16, hipLaunchKernelGGL(chan_stats_kernel<T>, dim3(nch, pg.N), dim3(256), 0, st, (const T*)a.x, a.partial, P, C, nch));
-        hipLaunchKernelGGL(bn_finish_kernel, dim3((C + 255) / 256), dim3(256), 0, st, a.partial, a.stats, a.running_mean, a.running_var,
+        hipLaunchKernelGGL(bn_finish_kernel, dim3((C + 31) / 32), dim3(256), 0, st, a.partial, a.stats, a.running_mean, a.running_var,
                            pg.N, P, C, nch, a.eps, a.momentum);
     } else {
         hipLaunchKernelGGL(bn_eval_stats_kernel, dim3((C + 255) / 256), dim3(256), 0, st, a.running_mean, a.running_var, a.stats, C, a.eps);
@@ -465,7 +507,7 @@ hipError_t bn_relu_pool_bwd_launch(const NormArgs& a, const PoolGeom& pg, hipStr
     const int nch = norm_chunks(P);
     HVC_DISPATCH_T(a.is_bf16, hipLaunchKernelGGL(bn_relu_pool_bwd_reduce_kernel<T>, dim3(nch, pg.N), dim3(256), 0, st, (const T*)a.x, (const T*)a.dy,
                                                  a.amax, a.stats, a.gamma, a.beta, a.partial, pg, nch));
-    hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3((C + 255) / 256), dim3(256), 0, st, a.partial, a.dgamma, a.dbeta, a.gsum, pg.N, P, C, nch);
+    hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3((C + 31) / 32), dim3(256), 0, st, a.partial, a.dgamma, a.dbeta, a.gsum, pg.N, P, C, nch);
     HVC_DISPATCH_T(a.is_bf16, hipLaunchKernelGGL(bn_relu_pool_bwd_apply_kernel<T>, dim3(grid_for((int64_t)pg.N * P * C / 8)), dim3(256), 0, st,
                                                  (const T*)a.x, (const T*)a.dy, a.amax, (T*)a.dx, a.stats, a.gsum, a.gamma, a.beta, pg, a.training));
     return hipGetLastError();

@@ -181,33 +181,29 @@ __device__ __forceinline__ void axis_range(int i, const AxisMap& m, int out, int
     hi = min(out - 1, (int)ceilf((i + 1) / m.r) + 2);
 }
 
+// One wave per coarse voxel: the 64 lanes stride over the fine voxels in its support box and the partial sums
+// are folded with a wavefront reduction (fixed order -> deterministic).
 __global__ __launch_bounds__(256) void trilinear_bwd_kernel(const float* __restrict__ dout, float* __restrict__ dsrc,
                                                              int B, int d, int h, int w, int D, int H, int W, int ac) {
     const AxisMap md = axis_map(d, D, ac), mh = axis_map(h, H, ac), mw = axis_map(w, W, ac);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t total = (int64_t)B * d * h * w;
-    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    for (int64_t idx = (int64_t)blockIdx.x * 4 + wave; idx < total; idx += (int64_t)gridDim.x * 4) {
         const Pos s = decode(idx, d, h, w);
         int dlo, dhi, hlo, hhi, wlo, whi;
         axis_range(s.d, md, D, dlo, dhi);
         axis_range(s.h, mh, H, hlo, hhi);
         axis_range(s.w, mw, W, wlo, whi);
+        const int nd = dhi - dlo + 1, nh = hhi - hlo + 1, nw = whi - wlo + 1;
         const float* g = dout + (int64_t)s.b * D * H * W;
         float acc = 0.f;
-        for (int od = dlo; od <= dhi; ++od) {
-            const float wd = axis_w(od, s.d, md, d);
-            if (wd == 0.f) continue;
-            for (int oh = hlo; oh <= hhi; ++oh) {
-                const float wh = axis_w(oh, s.h, mh, h);
-                if (wh == 0.f) continue;
-                float row = 0.f;
-                for (int ow = wlo; ow <= whi; ++ow) {
-                    const float ww = axis_w(ow, s.w, mw, w);
-                    if (ww != 0.f) row += ww * g[((int64_t)od * H + oh) * W + ow];
-                }
-                acc += wd * wh * row;
-            }
+        for (int e = lane; e < nd * nh * nw; e += 64) {
+            const int ow = wlo + e % nw, oh = hlo + (e / nw) % nh, od = dlo + e / (nw * nh);
+            const float wgt = axis_w(od, s.d, md, d) * axis_w(oh, s.h, mh, h) * axis_w(ow, s.w, mw, w);
+            if (wgt != 0.f) acc += wgt * g[((int64_t)od * H + oh) * W + ow];
         }
-        dsrc[idx] = acc;
+        acc = wave_sum(acc);
+        if (lane == 0) dsrc[idx] = acc;
     }
 }
 
@@ -253,7 +249,7 @@ hipError_t trilinear_launch(const float* src, float* dst, int B, int d, int h, i
                             hipStream_t st) {
     const int ac = align_corners ? 1 : 0;
     if (!bwd) hipLaunchKernelGGL(trilinear_fwd_kernel, dim3(grid_for((int64_t)B * D * H * W)), dim3(256), 0, st, src, dst, B, d, h, w, D, H, W, ac);
-    else hipLaunchKernelGGL(trilinear_bwd_kernel, dim3(grid_for((int64_t)B * d * h * w)), dim3(256), 0, st, src, dst, B, d, h, w, D, H, W, ac);
+    else hipLaunchKernelGGL(trilinear_bwd_kernel, dim3(grid_for((int64_t)B * d * h * w * 64)), dim3(256), 0, st, src, dst, B, d, h, w, D, H, W, ac);
     return hipGetLastError();
 }
 
