@@ -135,7 +135,7 @@ __device__ __forceinline__ void load_row_frags(const T* rowp, int h, bool valid,
 // forward
 // ---------------------------------------------------------------------------------
 template <typename T, int D, bool DROP, bool VEC>
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a) {
+__global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnArgs a) {
     constexpr int NS = NSplit<T>::value;
     constexpr int TILE = kKT * D;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -498,8 +498,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a) 
     const int r = lane & 31, h = lane >> 5;
 
     const int nkb = (a.Nk + kQB - 1) / kQB;
+    const int nwg = nkb * a.B * a.H;
+    const int split = blockIdx.x / nwg;          // query-range slice (0 when qsplit == 1)
     int bh, kb;
-    block_map(blockIdx.x, a.B * a.H, nkb, bh, kb);
+    block_map(blockIdx.x % nwg, a.B * a.H, nkb, bh, kb);
     const int b = bh / a.H, hh = bh % a.H;
     const T* qp = reinterpret_cast<const T*>(a.q) + b * a.q_sb + hh * a.q_sh;
     const T* kp = reinterpret_cast<const T*>(a.k) + b * a.k_sb + hh * a.k_sh;
@@ -520,7 +522,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a) 
     TileLoader<T, D, VEC> ql, dl;
     auto Qt = [&](int buf) { return lds + (buf * 2 + 0) * NS * TILE; };
     auto Dt = [&](int buf) { return lds + (buf * 2 + 1) * NS * TILE; };
-    const int nt = (a.Nq + kKT - 1) / kKT;
+    const int nt_all = (a.Nq + kKT - 1) / kKT;
+    const int per_split = (nt_all + a.qsplit - 1) / a.qsplit;
+    const int t_begin = split * per_split;
+    const int nt = min(nt_all, t_begin + per_split);      // this workgroup sweeps query tiles [t_begin, nt)
     float st_l = 0.f, st_d = 0.f;
     auto issue_stat = [&](int t) {
         if (tid < kKT) {
@@ -552,13 +557,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a) 
             }
         }
     };
-    ql.issue(qp, a.q_sn, 0, a.Nq, tid);
-    dl.issue(dop, a.do_sn, 0, a.Nq, tid);
-    issue_stat(0);
-    ql.commit(Qt(0), tid);
-    dl.commit(Dt(0), tid);
-    commit_stat(0);
-    gen_lots(0, 0);
+    ql.issue(qp, a.q_sn, t_begin * kKT, a.Nq, tid);
+    dl.issue(dop, a.do_sn, t_begin * kKT, a.Nq, tid);
+    issue_stat(t_begin);
+    ql.commit(Qt(t_begin & 1), tid);
+    dl.commit(Dt(t_begin & 1), tid);
+    commit_stat(t_begin & 1);
+    gen_lots(t_begin, t_begin & 1);
     __syncthreads();
 
     const float sl2 = a.scale * kLog2e;
@@ -569,7 +574,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a) 
         for (int i = 0; i < 16; ++i) { dk[dt][i] = 0.f; dv[dt][i] = 0.f; }
     const int kcol = wave * 32 + r;          // this lane's key column in the lots tile
 
-    for (int t = 0; t < nt; ++t) {
+    for (int t = t_begin; t < nt; ++t) {
         const int buf = t & 1;
         if (t + 1 < nt) {
             ql.issue(qp, a.q_sn, (t + 1) * kKT, a.Nq, tid);
@@ -651,6 +656,22 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a) 
     }
     // tiles: rows = key (registers), col = d (lane)
     const float ks = DROP ? a.keep_scale : 1.f;
+    if (a.qsplit > 1) {   // fp32 partial slabs [dK|dV][split][bh][key][d]; summed in a fixed order by attn_dkv_reduce_kernel
+        const size_t slab = (size_t)a.B * a.H * a.Nk * D;
+        float* pk = a.dkv_partial + ((size_t)split * a.B * a.H + bh) * a.Nk * D;
+        float* pv = pk + (size_t)a.qsplit * slab;
+#pragma unroll
+        for (int dt = 0; dt < D / 32; ++dt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int kk = k0 + acc_row(i, h);
+                if (kk < a.Nk) {
+                    pk[(size_t)kk * D + 32 * dt + r] = dk[dt][i] * a.scale * ks;
+                    pv[(size_t)kk * D + 32 * dt + r] = dv[dt][i] * ks;
+                }
+            }
+        return;
+    }
 #pragma unroll
     for (int dt = 0; dt < D / 32; ++dt)
 #pragma unroll
@@ -661,6 +682,25 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a) 
                 dvp[(int64_t)kk * a.dv_sn + 32 * dt + r] = from_f<T>(dv[dt][i] * ks);
             }
         }
+}
+
+// dK / dV = sum over the query-range slices of the partial slabs (fixed order), cast and scattered to the strided outputs
+template <typename T, int D>
+__global__ __launch_bounds__(256) void attn_dkv_reduce_kernel(const AttnArgs a) {
+    const size_t slab = (size_t)a.B * a.H * a.Nk * D;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < slab; e += (size_t)gridDim.x * 256) {
+        const int d = (int)(e % D);
+        const int key = (int)((e / D) % a.Nk);
+        const int bh = (int)(e / ((size_t)D * a.Nk));
+        const int b = bh / a.H, hh = bh % a.H;
+        float sk = 0.f, sv = 0.f;
+        for (int s = 0; s < a.qsplit; ++s) {
+            sk += a.dkv_partial[(size_t)s * slab + e];
+            sv += a.dkv_partial[((size_t)a.qsplit + s) * slab + e];
+        }
+        reinterpret_cast<T*>(a.dk)[b * a.dk_sb + hh * a.dk_sh + (int64_t)key * a.dk_sn + d] = from_f<T>(sk);
+        reinterpret_cast<T*>(a.dv)[b * a.dv_sb + hh * a.dv_sh + (int64_t)key * a.dv_sn + d] = from_f<T>(sv);
+    }
 }
 
 template <typename T, int D>
@@ -701,9 +741,22 @@ hipError_t launch_bwd(const AttnArgs& a, hipStream_t st) {
         auto k = attn_bwd_dkv_kernel<T, D, DROP, VEC>;
         hipError_t e = set_lds(k, lds);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k, dim3(nkb * a.B * a.H), dim3(256), lds, st, a);
+        // Few key blocks (cross-attention, small contexts) leave most CUs idle: slice the query range over more
+        // workgroups and sum the fp32 partial dK / dV slabs in a second, deterministic pass.
+        AttnArgs b = a;
+        b.qsplit = attention_bwd_qsplit(a.B, a.H, a.Nq, a.Nk);
+        if (b.qsplit > 1 && (!a.dkv_partial || a.partial_floats < (int64_t)2 * b.qsplit * a.B * a.H * a.Nk * D)) b.qsplit = 1;
+        hipLaunchKernelGGL(k, dim3(nkb * a.B * a.H * b.qsplit), dim3(256), lds, st, b);
         e = hipGetLastError();
         if (e != hipSuccess) return e;
+        if (b.qsplit > 1) {
+            size_t n = (size_t)a.B * a.H * a.Nk * D;
+            int blocks = (int)((n + 255) / 256);
+            if (blocks > 4096) blocks = 4096;
+            hipLaunchKernelGGL((attn_dkv_reduce_kernel<T, D>), dim3(blocks), dim3(256), 0, st, b);
+            e = hipGetLastError();
+            if (e != hipSuccess) return e;
+        }
     }
     if (ph & 4) {
         const int nqb = (a.Nq + kQB - 1) / kQB;
@@ -732,6 +785,15 @@ hipError_t dispatch(const AttnArgs& a, bool bwd, hipStream_t st) {
 }
 
 }  // namespace
+
+int attention_bwd_qsplit(int B, int H, int Nq, int Nk) {
+    const int wgs = ((Nk + kQB - 1) / kQB) * B * H;
+    const int nt = (Nq + kKT - 1) / kKT;
+    if (wgs >= 512 || nt < 16) return 1;
+    int want = (768 + wgs - 1) / wgs;
+    if (want > nt / 8) want = nt / 8;          // >= 8 query tiles per slice
+    return want < 2 ? 1 : want;
+}
 
 hipError_t attention_launch(const AttnArgs& a, bool bwd, hipStream_t st) {
     return a.is_bf16 ? dispatch<bf16>(a, bwd, st) : dispatch<float>(a, bwd, st);

@@ -97,8 +97,14 @@ int hvc_attention_fwd(const void* q, const void* k, const void* v, void* o, floa
     return hip_result(hvc::attention_launch(a, false, (hipStream_t)stream), "attention_fwd");
 }
 
+int64_t hvc_attention_bwd_workspace(int B, int H, int Nq, int Nk, int D) {
+    if (B < 1 || H < 1 || Nq < 1 || Nk < 1 || D < 1) return -1;
+    const int qs = hvc::attention_bwd_qsplit(B, H, Nq, Nk);
+    return (int64_t)B * H * Nq + (qs > 1 ? (int64_t)2 * qs * B * H * Nk * D : 0);
+}
+
 int hvc_attention_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout,
-                      const float* lse, float* delta_ws, void* dq, void* dk, void* dv,
+                      const float* lse, float* workspace, void* dq, void* dk, void* dv,
                       int B, int H, int Nq, int Nk, int D,
                       int64_t q_sb, int64_t q_sn, int64_t q_sh, int64_t k_sb, int64_t k_sn, int64_t k_sh,
                       int64_t v_sb, int64_t v_sn, int64_t v_sh, int64_t o_sb, int64_t o_sn, int64_t o_sh,
@@ -108,8 +114,11 @@ int hvc_attention_bwd(const void* q, const void* k, const void* v, const void* o
     if (rc) return rc;
     if (phases < 0 || phases > 7) return fail(HVC_E_BADARG, "attention_bwd: phases is a 3-bit mask");
     a.phases = phases;
-    if (!o || !dout || !lse || !delta_ws || !dq || !dk || !dv) return fail(HVC_E_BADARG, "attention_bwd: null operand");
-    a.o = const_cast<void*>(o); a.dout = dout; a.lse = const_cast<float*>(lse); a.delta = delta_ws;
+    if (!o || !dout || !lse || !workspace || !dq || !dk || !dv) return fail(HVC_E_BADARG, "attention_bwd: null operand");
+    a.o = const_cast<void*>(o); a.dout = dout; a.lse = const_cast<float*>(lse); a.delta = workspace;
+    a.qsplit = 1;
+    a.dkv_partial = workspace + (int64_t)B * H * Nq;
+    a.partial_floats = hvc_attention_bwd_workspace(B, H, Nq, Nk, D) - (int64_t)B * H * Nq;
     a.dq = dq; a.dk = dk; a.dv = dv;
     a.vec = a.vec && aligned16(q) && aligned16(k) && aligned16(v) && aligned16(o) && aligned16(dout);
     return hip_result(hvc::attention_launch(a, true, (hipStream_t)stream), "attention_bwd");

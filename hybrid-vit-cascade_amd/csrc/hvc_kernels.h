@@ -28,9 +28,13 @@ struct AttnArgs {
     float keep_scale;       // 1 / (1 - p)
     int vec;                // 16-byte vector access legal for every operand
     int phases;             // bwd: bit 0 delta, bit 1 dK/dV kernel, bit 2 dQ kernel (0 = all)
+    int qsplit;             // dK/dV kernel: number of query-range slices per key block (filled by the launcher)
+    float* dkv_partial;     // [2][qsplit][B*H][Nk][D] fp32 partial dK / dV slabs when qsplit > 1
+    int64_t partial_floats; // capacity of dkv_partial
     int is_bf16;
 };
 hipError_t attention_launch(const AttnArgs& a, bool bwd, hipStream_t st);
+int attention_bwd_qsplit(int B, int H, int Nq, int Nk);
 
 enum GemmAct { kActNone = 0, kActGelu = 1, kActGeluGrad = 2 };
 

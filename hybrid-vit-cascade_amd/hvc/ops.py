@@ -121,7 +121,7 @@ def attention_bwd(q, k, v, o, dout, lse, scale, p_drop=0.0, seed=0, dq=None, dk=
     for g, x, n in ((dq, q, "dq"), (dk, k, "dk"), (dv, v, "dv")):
         if g.shape != x.shape or any(gs != xs for gs, xs, sz in zip(g.stride(), x.stride(), x.shape) if sz > 1):
             raise ValueError(f"attention_bwd: {n} must have the shape and strides of its primal")
-    delta = torch.empty((B, H, Nq), dtype=torch.float32, device=q.device)
+    delta = torch.empty((_lib.load().hvc_attention_bwd_workspace(B, H, Nq, Nk, D),), dtype=torch.float32, device=q.device)
     args = (q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), dout.data_ptr(), lse.data_ptr(),
             delta.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), B, H, Nq, Nk, D,
             *_bnhd_strides(q), *_bnhd_strides(k), *_bnhd_strides(v), *_bnhd_strides(o),

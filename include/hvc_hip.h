@@ -61,13 +61,17 @@ int hvc_attention_fwd(const void* q, const void* k, const void* v, void* o, floa
                       int64_t o_sb, int64_t o_sn, int64_t o_sh,
                       float scale, float p_drop, uint64_t seed, int dtype, void* stream);
 
-/* Gradient of the above (autograd of the same reference lines).  delta_ws: [B*H][Nq] fp32 scratch.
+/* Floats of scratch hvc_attention_bwd needs: B*H*Nq for delta, plus fp32 partial dK/dV slabs when few key blocks
+ * (cross-attention) make the dK/dV kernel slice the query range over extra workgroups. */
+int64_t hvc_attention_bwd_workspace(int B, int H, int Nq, int Nk, int D);
+
+/* Gradient of the above (autograd of the same reference lines).  workspace: hvc_attention_bwd_workspace floats.
  * dq/dk/dv use the strides of q/k/v respectively; dout uses the strides of o.
  * Three launches: delta = rowsum(dO * O) (bit 0 of `phases`), the dK/dV kernel (bit 1), the dQ kernel (bit 2);
  * phases = 0 or 7 runs all of them, a sub-mask lets a caller time them separately (they must still be issued in
  * that order on one stream). */
 int hvc_attention_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout,
-                      const float* lse, float* delta_ws, void* dq, void* dk, void* dv,
+                      const float* lse, float* workspace, void* dq, void* dk, void* dv,
                       int B, int H, int Nq, int Nk, int D,
                       int64_t q_sb, int64_t q_sn, int64_t q_sh,
                       int64_t k_sb, int64_t k_sn, int64_t k_sh,

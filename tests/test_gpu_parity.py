@@ -247,7 +247,8 @@ def test_direct_regression_small_vs_golden(golden, train, mode):
 # kernel-level checks through the C ABI against the oracle, incl. ragged / edge shapes
 # ----------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("shape", [(1, 1, 1, 1, 32), (2, 3, 65, 1, 64), (1, 2, 129, 257, 32), (2, 4, 128, 64, 64),
-                                   (1, 1, 31, 63, 64)])
+                                   (1, 1, 31, 63, 64),
+                                   (1, 2, 2048, 64, 32), (1, 1, 1100, 130, 64)])   # few key blocks: query-range-sliced dK/dV
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_attention_kernel_edge_shapes(shape, dtype):
     from hvc import ops
