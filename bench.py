@@ -16,6 +16,7 @@ Workloads (BASELINE.json configs):
   direct64  (configs[1]): 64^3, batch 4, bf16, 4096 tokens.
 """
 import argparse
+import math
 import json
 import os
 import sys
@@ -195,6 +196,8 @@ def main():
         torch.cuda.synchronize()
         ops.PROFILE = None
 
+    if not math.isfinite(float(loss.item())):
+        raise RuntimeError(f"rank {rank}: non-finite training loss {loss.item()} after {args.warmup + args.steps} steps - the measurement is void")
     if rank == 0:
         vols = wl["batch"] * world * args.steps
         value = vols / elapsed

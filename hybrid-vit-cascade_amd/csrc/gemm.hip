@@ -232,7 +232,27 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) bj[e] = (g.bias && e < nj) ? g.bias[j + e] : 0.f;
 
-    for (int row = tid >> 4; row < kBM; row += 16) {
+    // Issue every global read of the epilogue (residual rows, saved pre-activations) before touching the staged tile,
+    // so the 8 row segments of a thread cost one memory round trip instead of eight dependent ones.
+    constexpr int RPT = kBM / 16;           // rows per thread
+    float rres[RPT][8], rpre[RPT][8];
+    if (g.residual) {
+#pragma unroll
+        for (int it = 0; it < RPT; ++it) {
+            const int i = i0 + (tid >> 4) + 16 * it;
+            if (i < g.M) load_n<float>(g.residual + (int64_t)(g.residual_rows > 0 ? i % g.residual_rows : i) * g.ldr + j, rres[it], nj, vec);
+        }
+    }
+    if (g.act == kActGeluGrad) {
+#pragma unroll
+        for (int it = 0; it < RPT; ++it) {
+            const int i = i0 + (tid >> 4) + 16 * it;
+            if (i < g.M) load_n<TO>(auxp + (int64_t)i * g.ldc + j, rpre[it], nj, vec);
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < RPT; ++it) {
+        const int row = (tid >> 4) + 16 * it;
         const int i = i0 + row;
         if (i >= g.M) break;
         float v[8];
@@ -248,10 +268,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
         } else if (g.act == kActGeluGrad) {
-            float pre[8];
-            load_n<TO>(auxp + co, pre, nj, vec);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] *= gelu_grad_f(pre[e]);
+            for (int e = 0; e < 8; ++e) v[e] *= gelu_grad_f(rpre[it][e]);
         }
         if (g.drop_thresh) {
             const uint64_t e0 = (uint64_t)i * (uint64_t)g.N + (uint64_t)j;     // even when vec (N, j multiples of 8)
@@ -269,24 +287,41 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
             for (int e = 0; e < 8; ++e) if (e < nj) v[e] *= gp[e];
         }
         if (g.residual) {
-            float rv[8];
-            load_n<float>(g.residual + (int64_t)(g.residual_rows > 0 ? i % g.residual_rows : i) * g.ldr + j, rv, nj, vec);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += rv[e];
+            for (int e = 0; e < 8; ++e) v[e] += rres[it][e];
         }
         store_n<TO>(Cp + co, v, nj, vec);
     }
 }
 
-template <typename TO>
+template <typename TO, bool VEC>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs g) {
     const size_t total = (size_t)g.M * g.N;
     TO* Cp = reinterpret_cast<TO*>(g.C);
-    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
-        float s = 0.f;
-        for (int k = 0; k < g.splitk; ++k) s += g.workspace[(size_t)k * total + e];   // fixed order: deterministic
+    if constexpr (VEC) {      // N % 4 == 0: one float4 per slab per thread, slabs summed in a fixed order (deterministic)
+        const size_t e = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+        if (e >= total) return;
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        int k = 0;
+        for (; k + 4 <= g.splitk; k += 4) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(g.workspace + (size_t)k * total + e);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(g.workspace + (size_t)(k + 1) * total + e);
+            const f32x4 c = *reinterpret_cast<const f32x4*>(g.workspace + (size_t)(k + 2) * total + e);
+            const f32x4 d = *reinterpret_cast<const f32x4*>(g.workspace + (size_t)(k + 3) * total + e);
+            s += a; s += b; s += c; s += d;
+        }
+        for (; k < g.splitk; ++k) s += *reinterpret_cast<const f32x4*>(g.workspace + (size_t)k * total + e);
         const size_t i = e / g.N, j = e % g.N;
-        Cp[i * g.ldc + j] = from_f<TO>(s * g.alpha);
+        TO* o = Cp + i * g.ldc + j;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) o[t] = from_f<TO>(s[t] * g.alpha);
+    } else {
+        for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+            float s = 0.f;
+            for (int k = 0; k < g.splitk; ++k) s += g.workspace[(size_t)k * total + e];
+            const size_t i = e / g.N, j = e % g.N;
+            Cp[i * g.ldc + j] = from_f<TO>(s * g.alpha);
+        }
     }
 }
 
@@ -318,9 +353,14 @@ hipError_t launch(const GemmArgs& g_in, hipStream_t st) {
     hipLaunchKernelGGL(k, dim3(tiles * g.splitk), dim3(256), lds, st, g);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || g.splitk == 1) return e;
-    int blocks = (int)(((size_t)g.M * g.N + 255) / 256);
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(splitk_reduce_kernel<TO>, dim3(blocks), dim3(256), 0, st, g);
+    if (g.N % 4 == 0 && (reinterpret_cast<uintptr_t>(g.workspace) & 15) == 0) {
+        const int blocks = (int)(((size_t)g.M * g.N / 4 + 255) / 256);
+        hipLaunchKernelGGL((splitk_reduce_kernel<TO, true>), dim3(blocks), dim3(256), 0, st, g);
+    } else {
+        int blocks = (int)(((size_t)g.M * g.N + 255) / 256);
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL((splitk_reduce_kernel<TO, false>), dim3(blocks), dim3(256), 0, st, g);
+    }
     return hipGetLastError();
 }
 

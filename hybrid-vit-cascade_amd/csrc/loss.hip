@@ -63,10 +63,13 @@ __global__ __launch_bounds__(256) void ssim_point_kernel(const float* __restrict
         const float a = m[0] * inv_win, b = m[1] * inv_win, epp = m[2] * inv_win, ett = m[3] * inv_win, ept = m[4] * inv_win;
         const float N1 = 2.f * a * b + C1, N2 = 2.f * (ept - a * b) + C2;
         const float D1 = a * a + b * b + C1, D2 = (epp - a * a) + (ett - b * b) + C2;
-        const float S = (N1 * N2) / (D1 * D2);
-        gmaps[idx] = S * (2.f * b / N1 - 2.f * b / N2 - 2.f * a / D1 + 2.f * a / D2);   // dS/dmu_p
+        // Derivatives are formed from dS/dN = N_other / (D1 D2), never by dividing S by a numerator: N2 (and N1)
+        // pass through zero for anti-correlated windows, where S / N2 would be 0/0.
+        const float inv = 1.f / (D1 * D2);
+        const float S = (N1 * N2) * inv;
+        gmaps[idx] = 2.f * b * (N2 - N1) * inv + 2.f * a * S * (1.f / D2 - 1.f / D1);   // dS/dmu_p
         gmaps[nvox + idx] = -S / D2;                                                      // dS/dE[p^2]
-        gmaps[2 * nvox + idx] = 2.f * S / N2;                                             // dS/dE[pt]
+        gmaps[2 * nvox + idx] = 2.f * N1 * inv;                                           // dS/dE[pt]
         accS += S;
         accL += fabsf(p[idx] - t[idx]);
     }

@@ -10,9 +10,46 @@
 namespace hvc {
 namespace {
 
-// grid = nbatch * bpb blocks; block = 256 threads, thread t owns columns t, t+256, ... (<= 4096 cols)
-template <typename TO>
+// 8 consecutive values <-> floats with one 16-byte (bf16) / two 16-byte (fp32) accesses
+template <typename T>
+__device__ __forceinline__ void ld8(const T* p, float (&v)[8]) {
+    Chunk8<T> c = load_chunk<T>(p, 8, true);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = chunk_get<T>(c, j);
+}
+template <typename T>
+__device__ __forceinline__ void st8(T* p, const float (&v)[8]) {
+    if constexpr (sizeof(T) == 2) {
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = f2bf(v[j]);
+        *reinterpret_cast<bf16x8*>(p) = o;
+    } else {
+        *reinterpret_cast<f32x4*>(p) = f32x4{v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<f32x4*>(p + 4) = f32x4{v[4], v[5], v[6], v[7]};
+    }
+}
+
+// Fold the per-thread column partials of one block: thread (rl, c8) holds 8 columns of row-lane rl; result
+// out[c] = sum over row lanes in a fixed order.  red: [rlanes][N] floats.
+__device__ __forceinline__ void fold_rows(const float (&acc)[8], int rl, int c8, int rlanes, int N, float* red, float* out, bool active) {
+    if (active) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) red[(size_t)rl * N + c8 * 8 + j] = acc[j];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < N; c += 256) {
+        float s = 0.f;
+        for (int l = 0; l < rlanes; ++l) s += red[(size_t)l * N + c];
+        out[c] = s;
+    }
+    __syncthreads();
+}
+
+// grid = nbatch * bpb blocks.  VEC (N % 8 == 0, N <= 2048): thread = (row lane, 8-column chunk), 16/32-byte accesses.
+template <typename TO, bool VEC>
 __global__ __launch_bounds__(256) void branch_bwd_kernel(const BranchArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float red[];
     const int bpb = a.blocks_per_batch;
     const int bidx = blockIdx.x / bpb, blk = blockIdx.x % bpb;
     const int rpb = a.rows_per_batch;
@@ -20,23 +57,64 @@ __global__ __launch_bounds__(256) void branch_bwd_kernel(const BranchArgs a) {
     const int r0 = blk * per, r1 = min(rpb, r0 + per);
     const TO* z = reinterpret_cast<const TO*>(a.z);
     TO* dz = reinterpret_cast<TO*>(a.dz);
-    for (int c = threadIdx.x; c < a.N; c += 256) {
-        const float gt = a.gate ? a.gate[(int64_t)bidx * a.N + c] : 1.f;
-        float sg = 0.f, sb = 0.f;
-        for (int rr = r0; rr < r1; ++rr) {
-            const int64_t e = ((int64_t)bidx * rpb + rr) * a.N + c;
-            const float d = a.dy[e];
-            float v = d * gt;
-            if (a.drop_thresh) {
-                const uint32_t bits = rng_pair(a.seed_lo, a.seed_hi, (uint32_t)((uint64_t)e >> 1), (uint32_t)((uint64_t)e >> 33));
-                v = (((bits >> (16 * (e & 1))) & 0xffffu) >= a.drop_thresh) ? v * a.keep_scale : 0.f;
+    float* pg = a.partial + ((size_t)blockIdx.x * 2 + 0) * a.N;
+    float* pb = a.partial + ((size_t)blockIdx.x * 2 + 1) * a.N;
+    if constexpr (VEC) {
+        const int c8n = a.N / 8;
+        const int rlanes = max(1, 256 / c8n);
+        const int c8 = threadIdx.x % c8n, rl = threadIdx.x / c8n;
+        const bool active = rl < rlanes && threadIdx.x < rlanes * c8n;
+        float gt[8], sg[8], sb[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { gt[j] = 1.f; sg[j] = 0.f; sb[j] = 0.f; }
+        if (active) {
+            if (a.gate) ld8<float>(a.gate + (int64_t)bidx * a.N + c8 * 8, gt);
+            for (int rr = r0 + rl; rr < r1; rr += rlanes) {
+                const int64_t e = ((int64_t)bidx * rpb + rr) * a.N + c8 * 8;
+                float d[8], v[8];
+                ld8<float>(a.dy + e, d);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = d[j] * gt[j];
+                if (a.drop_thresh) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const uint64_t el = (uint64_t)e + j;
+                        const uint32_t bits = rng_pair(a.seed_lo, a.seed_hi, (uint32_t)(el >> 1), (uint32_t)(el >> 33));
+                        v[j] = (((bits >> (16 * (el & 1))) & 0xffffu) >= a.drop_thresh) ? v[j] * a.keep_scale : 0.f;
+                    }
+                }
+                if (z) {
+                    float zz[8];
+                    ld8<TO>(z + e, zz);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) sg[j] += d[j] * zz[j];
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) sb[j] += v[j];
+                st8<TO>(dz + e, v);
             }
-            if (z) sg += d * to_f<TO>(z[e]);
-            sb += v;
-            dz[e] = from_f<TO>(v);
         }
-        a.partial[((size_t)blockIdx.x * 2 + 0) * a.N + c] = sg;
-        a.partial[((size_t)blockIdx.x * 2 + 1) * a.N + c] = sb;
+        fold_rows(sg, rl, c8, rlanes, a.N, red, pg, active);
+        fold_rows(sb, rl, c8, rlanes, a.N, red, pb, active);
+    } else {
+        for (int c = threadIdx.x; c < a.N; c += 256) {
+            const float gt = a.gate ? a.gate[(int64_t)bidx * a.N + c] : 1.f;
+            float sg = 0.f, sb = 0.f;
+            for (int rr = r0; rr < r1; ++rr) {
+                const int64_t e = ((int64_t)bidx * rpb + rr) * a.N + c;
+                const float d = a.dy[e];
+                float v = d * gt;
+                if (a.drop_thresh) {
+                    const uint32_t bits = rng_pair(a.seed_lo, a.seed_hi, (uint32_t)((uint64_t)e >> 1), (uint32_t)((uint64_t)e >> 33));
+                    v = (((bits >> (16 * (e & 1))) & 0xffffu) >= a.drop_thresh) ? v * a.keep_scale : 0.f;
+                }
+                if (z) sg += d * to_f<TO>(z[e]);
+                sb += v;
+                dz[e] = from_f<TO>(v);
+            }
+            pg[c] = sg;
+            pb[c] = sb;
+        }
     }
 }
 
@@ -58,15 +136,35 @@ __global__ __launch_bounds__(256) void branch_final_kernel(const BranchArgs a, i
     }
 }
 
-// grid.x = row blocks; thread t owns columns t, t+256...
-template <typename T>
+// grid.x = row blocks.  VEC: thread = (row lane, 8-column chunk).
+template <typename T, bool VEC>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* x, float* partial, int M, int N, int nblk) {
+    extern __shared__ __attribute__((aligned(16))) float red[];
     const int per = (M + nblk - 1) / nblk;
     const int r0 = blockIdx.x * per, r1 = min(M, r0 + per);
-    for (int c = threadIdx.x; c < N; c += 256) {
-        float s = 0.f;
-        for (int r = r0; r < r1; ++r) s += to_f<T>(x[(int64_t)r * N + c]);
-        partial[(size_t)blockIdx.x * N + c] = s;
+    float* out = partial + (size_t)blockIdx.x * N;
+    if constexpr (VEC) {
+        const int c8n = N / 8;
+        const int rlanes = max(1, 256 / c8n);
+        const int c8 = threadIdx.x % c8n, rl = threadIdx.x / c8n;
+        const bool active = threadIdx.x < rlanes * c8n;
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+        if (active)
+            for (int r = r0 + rl; r < r1; r += rlanes) {
+                float v[8];
+                ld8<T>(x + (int64_t)r * N + c8 * 8, v);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] += v[j];
+            }
+        fold_rows(acc, rl, c8, rlanes, N, red, out, active);
+    } else {
+        for (int c = threadIdx.x; c < N; c += 256) {
+            float s = 0.f;
+            for (int r = r0; r < r1; ++r) s += to_f<T>(x[(int64_t)r * N + c]);
+            out[c] = s;
+        }
     }
 }
 __global__ __launch_bounds__(256) void colsum_final_kernel(const float* partial, float* out, int N, int nblk) {
@@ -95,8 +193,16 @@ hipError_t branch_bwd_launch(const BranchArgs& a, hipStream_t st) {
     if (a.rows % a.rows_per_batch != 0) return hipErrorInvalidValue;
     const int nbatch = a.rows / a.rows_per_batch;
     dim3 grid((unsigned)(nbatch * a.blocks_per_batch)), blk(256);
-    if (a.out_bf16) hipLaunchKernelGGL(branch_bwd_kernel<bf16>, grid, blk, 0, st, a);
-    else hipLaunchKernelGGL(branch_bwd_kernel<float>, grid, blk, 0, st, a);
+    const bool vec = (a.N % 8 == 0) && a.N <= 2048 && (reinterpret_cast<uintptr_t>(a.dy) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.dz) & 15) == 0 &&
+                     (!a.z || (reinterpret_cast<uintptr_t>(a.z) & 15) == 0) && (!a.gate || (reinterpret_cast<uintptr_t>(a.gate) & 15) == 0);
+    const size_t lds = vec ? (size_t)max(1, 256 / (a.N / 8)) * a.N * sizeof(float) : 0;
+    if (a.out_bf16) {
+        if (vec) hipLaunchKernelGGL((branch_bwd_kernel<bf16, true>), grid, blk, lds, st, a);
+        else hipLaunchKernelGGL((branch_bwd_kernel<bf16, false>), grid, blk, 0, st, a);
+    } else {
+        if (vec) hipLaunchKernelGGL((branch_bwd_kernel<float, true>), grid, blk, lds, st, a);
+        else hipLaunchKernelGGL((branch_bwd_kernel<float, false>), grid, blk, 0, st, a);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (!a.dbias && !a.dgate) return hipSuccess;
@@ -105,8 +211,15 @@ hipError_t branch_bwd_launch(const BranchArgs& a, hipStream_t st) {
 }
 
 hipError_t colsum_launch(const void* x, float* partial, float* out, int M, int N, int nblk, int is_bf16, hipStream_t st) {
-    if (is_bf16) hipLaunchKernelGGL(colsum_kernel<bf16>, dim3(nblk), dim3(256), 0, st, reinterpret_cast<const bf16*>(x), partial, M, N, nblk);
-    else hipLaunchKernelGGL(colsum_kernel<float>, dim3(nblk), dim3(256), 0, st, reinterpret_cast<const float*>(x), partial, M, N, nblk);
+    const bool vec = (N % 8 == 0) && N <= 2048 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+    const size_t lds = vec ? (size_t)max(1, 256 / (N / 8)) * N * sizeof(float) : 0;
+    if (is_bf16) {
+        if (vec) hipLaunchKernelGGL((colsum_kernel<bf16, true>), dim3(nblk), dim3(256), lds, st, reinterpret_cast<const bf16*>(x), partial, M, N, nblk);
+        else hipLaunchKernelGGL((colsum_kernel<bf16, false>), dim3(nblk), dim3(256), 0, st, reinterpret_cast<const bf16*>(x), partial, M, N, nblk);
+    } else {
+        if (vec) hipLaunchKernelGGL((colsum_kernel<float, true>), dim3(nblk), dim3(256), lds, st, reinterpret_cast<const float*>(x), partial, M, N, nblk);
+        else hipLaunchKernelGGL((colsum_kernel<float, false>), dim3(nblk), dim3(256), 0, st, reinterpret_cast<const float*>(x), partial, M, N, nblk);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(colsum_final_kernel, dim3((N + 31) / 32), dim3(256), 0, st, partial, out, N, nblk);

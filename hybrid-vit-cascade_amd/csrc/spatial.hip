@@ -177,8 +177,11 @@ __device__ __forceinline__ float axis_w(int o, int i, const AxisMap& m, int in) 
 // conservative range of fine indices whose support can include coarse index i
 __device__ __forceinline__ void axis_range(int i, const AxisMap& m, int out, int& lo, int& hi) {
     if (m.r <= 0.f) { lo = 0; hi = out - 1; return; }
-    lo = max(0, (int)floorf((i - 1) / m.r) - 2);
-    hi = min(out - 1, (int)ceilf((i + 1) / m.r) + 2);
+    // src(o) in (i-1, i+1):  align_corners: o in ((i-1)/r, (i+1)/r);  else: o in ((i-0.5)/r - 0.5, (i+1.5)/r - 0.5); +-1 for rounding
+    const float a = m.ac ? (i - 1) / m.r : (i - 0.5f) / m.r - 0.5f;
+    const float b = m.ac ? (i + 1) / m.r : (i + 1.5f) / m.r - 0.5f;
+    lo = max(0, (int)floorf(a) - 1);
+    hi = min(out - 1, (int)ceilf(b) + 1);
 }
 
 // One wave per coarse voxel: the 64 lanes stride over the fine voxels in its support box and the partial sums

@@ -528,6 +528,31 @@ def test_multiscale_loss_stage1_matches_direct_loss():
     d["total_loss"].backward()
 
 
+def test_ssim_l1_loss_zero_crossing_numerators():
+    """SSIM numerators N1 = 2 mu_p mu_t + C1 and N2 = 2 cov + C2 cross zero for anti-correlated windows (early
+    training does this at 128^3); dS/dN must stay finite there, as in the reference's autograd of
+    model_direct.py:88-116 which never divides by a numerator."""
+    from direct_regression.model_direct import DirectRegressionLoss
+    from oracle import hvc_oracle as O
+    gen = torch.Generator().manual_seed(11)
+    t = torch.rand(1, 1, 24, 24, 24, generator=gen) * 2 - 1
+    ramp = torch.linspace(0.0, 0.01, 24).view(1, 1, 1, 1, 24)
+    p = -ramp * t                                   # covariance sweeps through -C2/2 along W
+    p[..., :12, :, :] = 0.01                        # constant window means: 2 mu_p mu_t + C1 == 0 in the interior
+    t[..., :12, :, :] = -0.005
+    pr = p.clone().requires_grad_(True)
+    ref = O.direct_regression_loss(pr, t)
+    ref["total_loss"].backward()
+    pg = p.to(dev()).requires_grad_(True)
+    got = DirectRegressionLoss(1.0, 0.5)(pg, t.to(dev()))
+    got["total_loss"].backward()
+    assert torch.isfinite(pg.grad).all()
+    for k in ("total_loss", "l1_loss", "ssim_loss"):
+        assert abs(got[k].item() - ref[k].item()) < 1e-5
+    err = (pg.grad.cpu() - pr.grad).norm() / pr.grad.norm()
+    assert err < 1e-3, err                          # fp32, north_star tolerance
+
+
 def _ddp_gpu_worker(rank, world, port, out_dir):
     import os
     import sys
