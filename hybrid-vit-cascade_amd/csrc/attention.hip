@@ -56,14 +56,34 @@ struct TileLoader {
     static constexpr int CHUNKS = kKT * CPR;           // per tile image
     static constexpr int CPT = CHUNKS / 256;           // chunks per thread
     Chunk8<T> reg[CPT];
+    const T* next[CPT];                                // this thread's chunk addresses in the next tile (VEC path)
+    int64_t step;                                      // elements between consecutive tiles
 
-    __device__ __forceinline__ void issue(const T* base, int64_t sn, int row0, int nrows, int tid) {
+    // row0 = first row of the first tile this loader will be asked for; tiles are then requested in order.
+    __device__ __forceinline__ void init(const T* base, int64_t sn, int row0, int tid) {
+        step = (int64_t)kKT * sn;
 #pragma unroll
         for (int i = 0; i < CPT; ++i) {
             int c = tid + 256 * i;
-            int row = c / CPR, ch = c % CPR;
-            reg[i] = load_row_chunk<T, VEC>(base, sn, row0 + row, nrows, ch * 8);
+            next[i] = base + (int64_t)(row0 + c / CPR) * sn + (c % CPR) * 8;
         }
+    }
+    // Full tiles take the incremental addresses (one 64-bit add per chunk, no bounds selects); a ragged or
+    // unaligned tile goes through the clamped / per-element path.
+    __device__ __forceinline__ void issue(const T* base, int64_t sn, int row0, int nrows, int tid) {
+        if (VEC && row0 + kKT <= nrows) {
+#pragma unroll
+            for (int i = 0; i < CPT; ++i) reg[i] = load_chunk<T>(next[i], 8, true);
+        } else {
+#pragma unroll
+            for (int i = 0; i < CPT; ++i) {
+                int c = tid + 256 * i;
+                int row = c / CPR, ch = c % CPR;
+                reg[i] = load_row_chunk<T, VEC>(base, sn, row0 + row, nrows, ch * 8);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) next[i] += step;
     }
     // images: NS consecutive tiles of kKT*D bf16
     __device__ __forceinline__ void commit(bf16* images, int tid) {
@@ -80,11 +100,15 @@ struct TileLoader {
 };
 
 // ---- attention-probability dropout ------------------------------------------------------------------
-// keep(b,h,q,k) = lot16(k & 3 of hash4(rowkey(b,h,q) + (k >> 2) * C)) >= thresh.  rowkey is one 32-bit word
-// per query row (computed once per lane, or once per LDS tile row in the dKV kernel); one
-// multiply-xorshift round with two multipliers yields four 16-bit lots, i.e. four consecutive keys
-// share the hash and each element costs a compare and a select.  The 1/(1-p) factor is applied once
-// to the accumulators in the epilogues, not per element.
+// keep(b,h,q,k) = lot16(k & 3 of hash4(rowkey(b,h,q) + (k >> 2) * C)) >= ts.  rowkey is one 32-bit word per
+// query row (computed once per lane, or once per LDS tile row in the dKV kernel); one multiply-xorshift round
+// with two multipliers yields two words of two 16-bit lots each, i.e. four consecutive keys share the hash.
+// Lots are read as SIGNED 16-bit numbers and the threshold is biased accordingly (ts = p * 65536 - 32768):
+//  * forward: a saturating packed subtract + packed arithmetic shift turn a word of two lots into a word of
+//    two 0x0000 / 0xffff keep masks, ANDed onto the packed bf16 probabilities (1.5 instructions / element);
+//  * backward: the high lot is a plain 32-bit signed compare of the whole word against ts << 16, the low
+//    lot a 16-bit compare - no field extraction.
+// The 1/(1-p) factor is applied once to the accumulators in the epilogues, not per element.
 __device__ __forceinline__ uint32_t drop_rowkey(const AttnArgs& a, int bh, int q) {
     return mix32(((uint32_t)(bh * a.Nq + q) * 0x9E3779B1u) ^ a.seed_lo) ^ a.seed_hi;
 }
@@ -97,12 +121,23 @@ __device__ __forceinline__ uint32_t drop_lots(uint32_t mixed, uint32_t mul) {   
     uint32_t y = mixed * mul;
     return y ^ (y >> 15);
 }
+__device__ __forceinline__ int drop_ts(const AttnArgs& a) { return (int)a.drop_thresh - 32768; }
+__device__ __forceinline__ bool drop_keep_lo(uint32_t w, int ts) { return (int16_t)w >= (int16_t)ts; }
+__device__ __forceinline__ bool drop_keep_hi(uint32_t w, int ts) { return (int32_t)w >= ts * 65536; }
 // keep flags of the four consecutive keys 4*(key>>2) .. +3
-__device__ __forceinline__ void drop_keep4(uint32_t rowkey, int key, uint32_t thresh, bool (&keep)[4]) {
+__device__ __forceinline__ void drop_keep4(uint32_t rowkey, int key, int ts, bool (&keep)[4]) {
     const uint32_t m = drop_mix(rowkey, (uint32_t)(key >> 2) * kKeyMul);
     const uint32_t a = drop_lots(m, kLotMulA), b = drop_lots(m, kLotMulB);
-    keep[0] = (a & 0xffffu) >= thresh; keep[1] = (a >> 16) >= thresh;
-    keep[2] = (b & 0xffffu) >= thresh; keep[3] = (b >> 16) >= thresh;
+    keep[0] = drop_keep_lo(a, ts); keep[1] = drop_keep_hi(a, ts);
+    keep[2] = drop_keep_lo(b, ts); keep[3] = drop_keep_hi(b, ts);
+}
+// word of two lots -> word of two 16-bit keep masks (0xffff = keep).  tm1x2 = (ts - 1) in both halves:
+// sat(ts - 1 - lot) is negative exactly when lot >= ts, and its sign fills the half.
+typedef short i16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t drop_keepmask2(uint32_t lots, uint32_t tm1x2) {
+    i16x2 d = __builtin_elementwise_sub_sat(__builtin_bit_cast(i16x2, tm1x2), __builtin_bit_cast(i16x2, lots));
+    d = d >> 15;
+    return __builtin_bit_cast(uint32_t, d);
 }
 
 __device__ __forceinline__ void block_map(int id, int nbh, int nblk, int& bh, int& blk) {
@@ -131,11 +166,29 @@ __device__ __forceinline__ void load_row_frags(const T* rowp, int h, bool valid,
     }
 }
 
+// Row fragments of c * row (the softmax scale * log2(e) rides on the register-resident operand, so the score
+// tiles leave the MFMA chain in exp2 units).
+template <typename T, int NS, int DS, bool VEC>
+__device__ __forceinline__ void load_row_frags_scaled(const T* rowp, int h, bool valid, float c, bf16x8 (&f)[NS][DS]) {
+#pragma unroll
+    for (int s = 0; s < DS; ++s) {
+        Chunk8<T> ch = VEC ? load_chunk<T>(rowp + 16 * s + 8 * h, 8, true) : load_chunk<T>(rowp + 16 * s + 8 * h, 8, false);
+        if (!valid) ch = zero_chunk<T>();
+        float x[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = chunk_get<T>(ch, j) * c;
+        bf16x8 im[NS];
+        acc_split<NS>(x, im);
+#pragma unroll
+        for (int t = 0; t < NS; ++t) f[t][s] = im[t];
+    }
+}
+
 // ---------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------
 template <typename T, int D, bool DROP, bool VEC>
-__global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnArgs a) {
+__global__ __launch_bounds__(256, sizeof(T) == 2 ? 3 : 2) void attn_fwd_kernel(const AttnArgs a) {
     constexpr int NS = NSplit<T>::value;
     constexpr int TILE = kKT * D;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -157,22 +210,31 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnArgs a) {
     const bool qvalid = qrow < a.Nq;
     const int qrow_c = qvalid ? qrow : a.Nq - 1;
 
+    // Q rows carry scale * log2(e): S^T = K (c Q)^T is already in exp2 units.
+    const float sl2 = a.scale * kLog2e;
     bf16x8 qf[NS][D / 16];
-    load_row_frags<T, NS, D / 16, VEC>(qp + (int64_t)qrow_c * a.q_sn, h, true, qf);
+    load_row_frags_scaled<T, NS, D / 16, VEC>(qp + (int64_t)qrow_c * a.q_sn, h, true, sl2, qf);
 
     TileLoader<T, D, VEC> kl, vl;
     auto Kt = [&](int buf) { return lds + (buf * 2 + 0) * NS * TILE; };
     auto Vt = [&](int buf) { return lds + (buf * 2 + 1) * NS * TILE; };
 
     const int nt = (a.Nk + kKT - 1) / kKT;
+    kl.init(kp, a.k_sn, 0, tid);
+    vl.init(vp, a.v_sn, 0, tid);
     kl.issue(kp, a.k_sn, 0, a.Nk, tid);
     vl.issue(vp, a.v_sn, 0, a.Nk, tid);
     kl.commit(Kt(0), tid);
     vl.commit(Vt(0), tid);
     __syncthreads();
 
-    const float sl2 = a.scale * kLog2e;
-    float msc = -INFINITY;      // reference max in exp2 units (max * sl2); p = exp2(s * sl2 - msc) <= 2^kRescaleLog2
+    // Reference exponent msc (exp2 units) of this lane's query row; p = exp2(s - msc) <= 2^kRescaleLog2.  -msc is
+    // kept replicated in a 16-register block that seeds the S^T accumulators, so the MFMA chain itself delivers
+    // s - msc and the exponentials need no per-element subtraction.
+    float msc = 0.f;
+    f32x16 negm;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) negm[i] = 0.f;
     float l = 0.f;
     f32x16 o[D / 32];
 #pragma unroll
@@ -181,6 +243,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnArgs a) {
         for (int i = 0; i < 16; ++i) o[dt][i] = 0.f;
 
     const uint32_t rowkey = DROP ? drop_rowkey(a, bh, qrow_c) : 0u;
+    const uint32_t tm1x2 = DROP ? ((uint32_t)(drop_ts(a) - 1) & 0xffffu) * 0x10001u : 0u;
 
     // One 64-key tile.  MASK is only instantiated for a ragged last tile, so the full tiles carry no
     // per-element bounds selects.
@@ -191,12 +254,11 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnArgs a) {
             kl.issue(kp, a.k_sn, (t + 1) * kKT, a.Nk, tid);
             vl.issue(vp, a.v_sn, (t + 1) * kKT, a.Nk, tid);
         }
-        // S^T[key][q] = K Q^T
+        // S^T[key][q] - msc[q] = K (c Q)^T + (-msc)
         f32x16 st[2];
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) st[kt][i] = 0.f;
+            st[kt] = negm;
 #pragma unroll
             for (int s = 0; s < D / 16; ++s) {
 #pragma unroll
@@ -216,46 +278,41 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnArgs a) {
                 for (int i = 0; i < 16; ++i)
                     if (kbase + 32 * kt + acc_row(i, h) >= a.Nk) st[kt][i] = -INFINITY;
         }
-        float mloc = -INFINITY;
+        float mloc = -INFINITY;      // row maximum relative to the reference
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
             for (int i = 0; i < 16; ++i) mloc = fmaxf(mloc, st[kt][i]);
-        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64)) * sl2;
-        // Deferred rescale: raise the reference max only when some row would overflow the 2^kRescaleLog2
-        // head-room (always on the first tile, where msc = -inf).  Wave-uniform branch; when taken, O, l
-        // and the reference are moved together, exactly once, before this tile's P is formed.
-        if (__any(mloc > msc + kRescaleLog2)) {
-            const float mnew = fmaxf(msc, mloc);
-            const float alpha = __builtin_amdgcn_exp2f(msc - mnew);
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+        // Deferred rescale: move the reference only when some row would overflow the 2^kRescaleLog2 head-room,
+        // and on the first tile, where every row adopts its own maximum.  Wave-uniform branch; when taken, O, l,
+        // the reference block and this tile's scores move together, exactly once, before P is formed.
+        if (t == 0 || __any(mloc > kRescaleLog2)) {
+            const float shift = t == 0 ? mloc : fmaxf(mloc, 0.f);
+            const float alpha = t == 0 ? 1.f : __builtin_amdgcn_exp2f(-shift);
             l *= alpha;
 #pragma unroll
             for (int dt = 0; dt < D / 32; ++dt)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) o[dt][i] *= alpha;
-            msc = mnew;
+            msc += shift;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) negm[i] = -msc;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) st[kt][i] -= shift;
         }
         float rs = 0.f;
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const float p = __builtin_amdgcn_exp2f(fmaf(st[kt][i], sl2, -msc));
+                const float p = __builtin_amdgcn_exp2f(st[kt][i]);
                 rs += p;
                 st[kt][i] = p;
             }
         l += rs;
-        if constexpr (DROP) {
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                for (int i = 0; i < 16; i += 4) {
-                    bool keep[4];
-                    drop_keep4(rowkey, kbase + 32 * kt + acc_row(i, h), a.drop_thresh, keep);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) st[kt][i + j] = keep[j] ? st[kt][i + j] : 0.f;
-                }
-        }
         // O^T[d][q] += V^T P^T
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
@@ -266,6 +323,22 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnArgs a) {
                 for (int j = 0; j < 8; ++j) x[j] = st[kt][8 * s2 + j];
                 bf16x8 pf[NS];
                 acc_split<NS>(x, pf);
+                if constexpr (DROP) {      // packed keep masks onto the bf16 pairs: registers 8 s2 .. + 7 = two 4-key groups
+#pragma unroll
+                    for (int g2 = 0; g2 < 2; ++g2) {
+                        const int key = kbase + 32 * kt + acc_row(8 * s2 + 4 * g2, h);
+                        const uint32_t m = drop_mix(rowkey, (uint32_t)(key >> 2) * kKeyMul);
+                        const uint32_t ma = drop_keepmask2(drop_lots(m, kLotMulA), tm1x2);
+                        const uint32_t mb = drop_keepmask2(drop_lots(m, kLotMulB), tm1x2);
+#pragma unroll
+                        for (int sa = 0; sa < NS; ++sa) {
+                            u32x4 w = __builtin_bit_cast(u32x4, pf[sa]);
+                            w[2 * g2] &= ma;
+                            w[2 * g2 + 1] &= mb;
+                            pf[sa] = __builtin_bit_cast(bf16x8, w);
+                        }
+                    }
+                }
 #pragma unroll
                 for (int dt = 0; dt < D / 32; ++dt) {
 #pragma unroll
@@ -370,29 +443,37 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
     const bool qvalid = qrow < a.Nq;
     const int qrow_c = qvalid ? qrow : a.Nq - 1;
 
+    // Q rows carry scale * log2(e); the S^T / dP^T accumulators start from -lse2[q] / -delta[q] (row constants of
+    // this lane's query), so the chains deliver s - lse2 and dP - delta without per-element arithmetic.
+    const float sl2 = a.scale * kLog2e;
     bf16x8 qf[NS][D / 16], dof[NS][D / 16];
-    load_row_frags<T, NS, D / 16, VEC>(qp + (int64_t)qrow_c * a.q_sn, h, true, qf);
+    load_row_frags_scaled<T, NS, D / 16, VEC>(qp + (int64_t)qrow_c * a.q_sn, h, true, sl2, qf);
     load_row_frags<T, NS, D / 16, VEC>(dop + (int64_t)qrow_c * a.do_sn, h, true, dof);
-    const float lse2 = a.lse[(int64_t)bh * a.Nq + qrow_c] * kLog2e;
-    const float delta = a.delta[(int64_t)bh * a.Nq + qrow_c] * (DROP ? 1.f / a.keep_scale : 1.f);
+    const float nlse2 = -a.lse[(int64_t)bh * a.Nq + qrow_c] * kLog2e;
+    const float ndelta = -a.delta[(int64_t)bh * a.Nq + qrow_c] * (DROP ? 1.f / a.keep_scale : 1.f);
+    f32x16 c_s, c_dp;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { c_s[i] = nlse2; c_dp[i] = ndelta; }
 
     TileLoader<T, D, VEC> kl, vl;
     auto Kt = [&](int buf) { return lds + (buf * 2 + 0) * NS * TILE; };
     auto Vt = [&](int buf) { return lds + (buf * 2 + 1) * NS * TILE; };
     const int nt = (a.Nk + kKT - 1) / kKT;
+    kl.init(kp, a.k_sn, 0, tid);
+    vl.init(vp, a.v_sn, 0, tid);
     kl.issue(kp, a.k_sn, 0, a.Nk, tid);
     vl.issue(vp, a.v_sn, 0, a.Nk, tid);
     kl.commit(Kt(0), tid);
     vl.commit(Vt(0), tid);
     __syncthreads();
 
-    const float sl2 = a.scale * kLog2e;
     f32x16 dq[D / 32];
 #pragma unroll
     for (int dt = 0; dt < D / 32; ++dt)
 #pragma unroll
         for (int i = 0; i < 16; ++i) dq[dt][i] = 0.f;
     const uint32_t rowkey = DROP ? drop_rowkey(a, bh, qrow_c) : 0u;
+    const int ts = drop_ts(a);
 
     auto tile = [&](auto mask_tag, int t) {
         constexpr bool MASK = decltype(mask_tag)::value;
@@ -404,8 +485,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
         f32x16 st[2], dpt[2];
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) { st[kt][i] = 0.f; dpt[kt][i] = 0.f; }
+            st[kt] = c_s;
+            dpt[kt] = c_dp;
 #pragma unroll
             for (int s = 0; s < D / 16; ++s) {
 #pragma unroll
@@ -429,13 +510,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
             for (int i = 0; i < 16; i += 4) {
                 const int key = kbase + 32 * kt + acc_row(i, h);
                 bool keep[4] = {true, true, true, true};
-                if constexpr (DROP) drop_keep4(rowkey, key, a.drop_thresh, keep);
+                if constexpr (DROP) drop_keep4(rowkey, key, ts, keep);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    float p = __builtin_amdgcn_exp2f(fmaf(st[kt][i + j], sl2, -lse2));
+                    float p = __builtin_amdgcn_exp2f(st[kt][i + j]);
                     if constexpr (MASK) { if (key + j >= a.Nk) p = 0.f; }
-                    const float d = keep[j] ? dpt[kt][i + j] : 0.f;
-                    st[kt][i + j] = p * (d - delta);
+                    const float d = keep[j] ? dpt[kt][i + j] : ndelta;      // keep * dP - delta
+                    st[kt][i + j] = p * d;
                 }
             }
         // dQ[q][d] += dS K  (dS^T accumulators as the A operand, K through the transposed read)
@@ -515,8 +596,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a) 
     const bool kvalid = krow < a.Nk;
     const int krow_c = kvalid ? krow : a.Nk - 1;
 
+    // K rows carry scale * log2(e) (scores in exp2 units); the S / dP accumulators of a query slice start from
+    // -lse2[q] / -delta[q] read from the tile's row constants, so p = exp2(acc) and dP - delta need no arithmetic.
+    const float sl2 = a.scale * kLog2e;
     bf16x8 kf[NS][D / 16], vf[NS][D / 16];
-    load_row_frags<T, NS, D / 16, VEC>(kp + (int64_t)krow_c * a.k_sn, h, kvalid, kf);
+    load_row_frags_scaled<T, NS, D / 16, VEC>(kp + (int64_t)krow_c * a.k_sn, h, kvalid, sl2, kf);
     load_row_frags<T, NS, D / 16, VEC>(vp + (int64_t)krow_c * a.v_sn, h, kvalid, vf);
 
     TileLoader<T, D, VEC> ql, dl;
@@ -531,8 +615,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a) 
         if (tid < kKT) {
             int q = t * kKT + tid;
             const bool ok = q < a.Nq;
-            st_l = ok ? a.lse[(int64_t)bh * a.Nq + q] * kLog2e : INFINITY;
-            st_d = ok ? a.delta[(int64_t)bh * a.Nq + q] * (DROP ? 1.f / a.keep_scale : 1.f) : 0.f;
+            st_l = ok ? -a.lse[(int64_t)bh * a.Nq + q] * kLog2e : -INFINITY;      // out-of-range query rows: p = exp2(-inf) = 0
+            st_d = ok ? -a.delta[(int64_t)bh * a.Nq + q] * (DROP ? 1.f / a.keep_scale : 1.f) : 0.f;
         }
     };
     auto commit_stat = [&](int buf) {
@@ -557,6 +641,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a) 
             }
         }
     };
+    ql.init(qp, a.q_sn, t_begin * kKT, tid);
+    dl.init(dop, a.do_sn, t_begin * kKT, tid);
     ql.issue(qp, a.q_sn, t_begin * kKT, a.Nq, tid);
     dl.issue(dop, a.do_sn, t_begin * kKT, a.Nq, tid);
     issue_stat(t_begin);
@@ -566,7 +652,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a) 
     gen_lots(t_begin, t_begin & 1);
     __syncthreads();
 
-    const float sl2 = a.scale * kLog2e;
+    const int ts = drop_ts(a);
     f32x16 dk[D / 32], dv[D / 32];
 #pragma unroll
     for (int dt = 0; dt < D / 32; ++dt)
@@ -586,7 +672,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a) 
             // S[q][key] = Q K^T ; dP[q][key] = dO V^T   (key on the lane)
             f32x16 s, dp;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
+            for (int g = 0; g < 4; ++g) {      // accumulator registers 4g .. 4g+3 <-> query rows 32 qt + 8 g + 4 h + {0..3}
+                const int ro = 32 * qt + 8 * g + 4 * h;
+                const f32x4 l4 = *reinterpret_cast<const f32x4*>(stat + (buf * 2 + 0) * kKT + ro);
+                const f32x4 d4 = *reinterpret_cast<const f32x4*>(stat + (buf * 2 + 1) * kKT + ro);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { s[4 * g + j] = l4[j]; dp[4 * g + j] = d4[j]; }
+            }
+            const f32x16 nd = dp;              // -delta rows again for the dropped elements
 #pragma unroll
             for (int ks = 0; ks < D / 16; ++ks) {
 #pragma unroll
@@ -605,21 +698,20 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a) 
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int ro = 32 * qt + 8 * g + 4 * h;
-                const f32x4 l4 = *reinterpret_cast<const f32x4*>(stat + (buf * 2 + 0) * kKT + ro);
-                const f32x4 d4 = *reinterpret_cast<const f32x4*>(stat + (buf * 2 + 1) * kKT + ro);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int i = 4 * g + j;
-                    const float p = __builtin_amdgcn_exp2f(fmaf(s[i], sl2, -l4[j]));
+                    const float p = __builtin_amdgcn_exp2f(s[i]);
                     float dpv = dp[i];
                     float pdv = p;
                     if constexpr (DROP) {   // 1/(1-p) is folded into delta (pre-divided) and the epilogue scales
-                        const bool keep = lots[((size_t)buf * kKT + ro + j) * kQB + kcol] >= a.drop_thresh;
+                        const bool keep = (int16_t)lots[((size_t)buf * kKT + ro + j) * kQB + kcol] >= (int16_t)ts;
                         pdv = keep ? p : 0.f;
-                        dpv = keep ? dpv : 0.f;
+                        dpv = keep ? dpv : nd[i];
+                        asm("" : "+v"(pdv));     // select in fp32, so that the bf16 conversions below stay packed pairs
                     }
                     pd[i] = pdv;
-                    ds[i] = p * (dpv - d4[j]);
+                    ds[i] = p * dpv;
                 }
             }
 #pragma unroll
