@@ -329,6 +329,47 @@ def test_attention_dropout_statistics_determinism_and_gradient_consistency():
         assert abs(fd - an) < 2e-2 * (abs(fd) + abs(an)) + 1e-3, (name, fd, an)
 
 
+@pytest.mark.parametrize("p", [0.1, 0.25])
+def test_attention_dropout_mask_is_bernoulli_like(p):
+    """Recover the full keep mask of the counter-based dropout (reference: nn.Dropout on the probabilities,
+    vit_components.py:48 / :105) and check it behaves like iid Bernoulli(1-p): global / per-row / per-column
+    rates and no serial correlation along keys (inside and across the 4-key hash groups), queries or heads."""
+    from hvc import ops
+    B, H, N, D = 1, 2, 256, 32
+    q = torch.zeros(B, N, H, D, device=dev())           # uniform probabilities 1/N, exactly representable
+    k = torch.zeros(B, N, H, D, device=dev())
+    cols = []
+    for c in range(N // D):                              # V = one-hot over the 32 keys of chunk c -> O[i, d] = keep(i, 32c + d) / (N (1-p))
+        v = torch.zeros(B, N, H, D, device=dev())
+        idx = torch.arange(D, device=dev())
+        v[:, 32 * c + idx, :, idx] = 1.0
+        o, _ = ops.attention_fwd(q, k, v, D ** -0.5, p, 4321)
+        cols.append(o * N * (1 - p))
+    m = torch.cat(cols, dim=-1).permute(0, 2, 1, 3).reshape(B * H, N, N)      # [bh][query][key]
+    assert ((m - m.round()).abs() < 1e-3).all() and set(m.round().unique().tolist()) <= {0.0, 1.0}
+    m = m.round().double().cpu()
+    n = m.numel()
+    sd = (p * (1 - p)) ** 0.5
+    assert abs(m.mean().item() - (1 - p)) < 4 * sd / n ** 0.5
+    assert (m.mean(dim=2) - (1 - p)).abs().max().item() < 5 * sd / N ** 0.5     # per query row
+    assert (m.mean(dim=1) - (1 - p)).abs().max().item() < 5 * sd / N ** 0.5     # per key column
+    z = (m - (1 - p)) / sd
+    def corr(a, b):
+        return (a * b).mean().item()
+    lim = 5 / (n / 2) ** 0.5
+    for lag in (1, 2, 3, 4, 5, 8, 64):                    # along keys: lags 1-3 mix in-group and cross-group pairs
+        assert abs(corr(z[:, :, :-lag], z[:, :, lag:])) < lim, ("key lag", lag)
+    for lag in (1, 2, 32):                                # along queries
+        assert abs(corr(z[:, :-lag, :], z[:, lag:, :])) < lim, ("query lag", lag)
+    assert abs(corr(z[0], z[1])) < lim                    # between heads
+    assert abs(corr(z[:, :-1, :-1], z[:, 1:, 1:])) < lim  # diagonal neighbours
+    # keys 4g .. 4g+3 share one hash evaluation: check every in-group pair separately
+    g = z.reshape(B * H, N, N // 4, 4)
+    for a in range(4):
+        for b in range(a + 1, 4):
+            assert abs(corr(g[..., a], g[..., b])) < 5 / (n / 4) ** 0.5, ("in-group", a, b)
+
+
 @pytest.mark.parametrize("M,N,K", [(1, 1, 8), (5, 7, 24), (130, 257, 72), (256, 128, 64)])
 @pytest.mark.parametrize("akm,bkm", [(False, False), (False, True), (True, True), (True, False)])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
