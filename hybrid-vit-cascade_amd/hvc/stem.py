@@ -125,9 +125,10 @@ def token_head(tokens, norm, output_proj, grid):
     return y.reshape(B, 1, *grid)
 
 
-def upsample_trilinear(vol, size):
-    """F.interpolate(trilinear, align_corners=True)   (reference models/hybrid_vit_backbone.py:272)."""
-    return HF.TrilinearFn.apply(vol, tuple(size))
+def upsample_trilinear(vol, size, align_corners=True):
+    """F.interpolate(trilinear): align_corners=True is the ViT head's upsample (reference models/hybrid_vit_backbone.py:272),
+    False the trainers' CT resize and the cascade's nn.Upsample (train_progressive_4gpu.py:46-57, model_progressive.py:169)."""
+    return HF.TrilinearFn.apply(vol, tuple(size), align_corners)
 
 
 def xray_encoder(encoder, xrays_flat):

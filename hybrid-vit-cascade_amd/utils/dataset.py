@@ -10,9 +10,15 @@ from hvc import synthetic
 
 
 class PatientDRRDataset(torch.utils.data.Dataset):
-    def __init__(self, data_path=None, target_xray_size=512, target_volume_size=(64, 64, 64), normalize_range=(-1, 1),
+    """Constructor as the reference (utils/dataset.py:34-45: data_path, target_xray_size=512,
+    target_volume_size=(256,256,256), ...).  The reference's progressive trainer calls it with
+    `root_dir=..., split=..., train_split=..., val_split=...` (train_progressive_4gpu.py:267-281), which its own class
+    rejects; here `root_dir` is an alias of `data_path` and `split` selects the contiguous train / val / test range."""
+
+    def __init__(self, data_path=None, target_xray_size=512, target_volume_size=(256, 256, 256), normalize_range=(-1, 1),
                  validate_alignment=False, augmentation=False, cache_in_memory=False, flip_drrs_vertical=False,
-                 max_patients=None, **_unused):
+                 max_patients=None, root_dir=None, split=None, train_split=0.8, val_split=0.1, **_unused):
+        data_path = data_path if data_path is not None else root_dir
         self.data_path = data_path
         self.target_xray_size = target_xray_size
         self.target_volume_size = tuple(target_volume_size)
@@ -24,17 +30,26 @@ class PatientDRRDataset(torch.utils.data.Dataset):
                 print("[hvc] nibabel is not installed: serving synthetic phantoms with the PatientDRRDataset contract")
                 self.synthetic = True
         if self.synthetic:
-            self.n = int(max_patients) if max_patients else 64
+            total = int(max_patients) if max_patients else 64
+            self.index = list(range(total))
         else:
             self.patients = sorted(d for d in os.listdir(data_path) if os.path.isdir(os.path.join(data_path, d)))
             if max_patients:
                 self.patients = self.patients[:max_patients]
-            self.n = len(self.patients)
+            self.index = list(range(len(self.patients)))
+        if split is not None:
+            if split not in ("train", "val", "test"):
+                raise ValueError(f"split must be 'train', 'val' or 'test', got {split!r}")
+            n = len(self.index)
+            a, b = int(train_split * n), int(train_split * n) + int(val_split * n)
+            self.index = {"train": self.index[:a], "val": self.index[a:b], "test": self.index[b:]}[split]
+        self.n = len(self.index)
 
     def __len__(self):
         return self.n
 
     def __getitem__(self, idx):
+        idx = self.index[idx]
         if self.synthetic:
             xr, ct = synthetic.sample(idx, self.target_volume_size, self.target_xray_size)
             return {"drr_stacked": xr, "ct_volume": ct, "patient_id": f"synthetic_{idx:04d}"}

@@ -124,3 +124,33 @@ def test_synthetic_dataset_contract():
     for k in ("drr_stacked", "ct_volume"):
         assert -1.0001 <= item[k].min().item() and item[k].max().item() <= 1.0001
     assert torch.equal(ds[1]["ct_volume"], item["ct_volume"])      # seeded: reproducible
+
+
+def test_dataset_split_ranges_of_the_progressive_trainer():
+    """train_progressive_4gpu.py:267-281 constructs the dataset with root_dir / split / train_split / val_split."""
+    from utils.dataset import PatientDRRDataset
+    kw = dict(root_dir=None, max_patients=10, train_split=0.8, val_split=0.1, target_xray_size=32, target_volume_size=(8, 8, 8))
+    parts = {s: PatientDRRDataset(split=s, **kw) for s in ("train", "val", "test")}
+    assert [len(parts[s]) for s in ("train", "val", "test")] == [8, 1, 1]
+    ids = [parts[s][i]["patient_id"] for s in ("train", "val", "test") for i in range(len(parts[s]))]
+    assert ids == [f"synthetic_{i:04d}" for i in range(10)]          # disjoint, ordered, complete
+    with pytest.raises(ValueError):
+        PatientDRRDataset(split="holdout", **kw)
+    import inspect
+    sig = inspect.signature(PatientDRRDataset.__init__)
+    assert sig.parameters["target_volume_size"].default == (256, 256, 256)   # reference utils/dataset.py:38
+
+
+def test_progressive_trainer_module_surface():
+    """Counterpart of direct_regression/progressive_cascade/train_progressive_4gpu.py: same entry points and config keys."""
+    import importlib, json, os
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import sys
+    sys.path.insert(0, os.path.join(here, "hybrid-vit-cascade_amd", "direct_regression"))
+    mod = importlib.import_module("progressive_cascade.train_progressive_4gpu")
+    for name in ("setup_ddp", "cleanup_ddp", "resize_ct_volume", "train_epoch", "validate", "train_stage", "main_worker", "main"):
+        assert callable(getattr(mod, name)), name
+    cfg = json.load(open(os.path.join(here, "hybrid-vit-cascade_amd", "direct_regression", "progressive_cascade", "config_progressive.json")))
+    assert cfg["training"]["stage2"] == {"num_epochs": 30, "batch_size": 2, "learning_rate": 5e-05, "target_resolution": [128, 128, 128]}
+    assert cfg["loss"]["stage3"]["drr"] == 0.3 and cfg["model"]["voxel_dim"] == 256
+    assert mod.STAGE_SIZES == {1: (64,) * 3, 2: (128,) * 3, 3: (256,) * 3}

@@ -594,6 +594,65 @@ def test_ssim_l1_loss_zero_crossing_numerators():
     assert err < 1e-3, err                          # fp32, north_star tolerance
 
 
+@pytest.mark.parametrize("align_corners", [True, False])
+@pytest.mark.parametrize("shape", [((1, 1, 1), (4, 4, 4)), ((4, 3, 5), (16, 9, 20)), ((16, 16, 16), (64, 64, 64)), ((7, 6, 5), (7, 6, 5)),
+                                   ((8, 8, 8), (4, 4, 4)), ((3, 3, 3), (10, 7, 1))])
+def test_trilinear_resize_kernels_vs_aten_semantics(shape, align_corners):
+    """F.interpolate(mode='trilinear') in both corner conventions (hybrid_vit_backbone.py:272 uses True;
+    model_progressive.py:169 / train_progressive_4gpu.py:46-57 use False), up- and down-sampling, forward and adjoint."""
+    import torch.nn.functional as F
+    from hvc import ops
+    (d, h, w), out = shape
+    g = torch.Generator().manual_seed(d * 100 + h * 10 + w)
+    x = torch.randn(2, d, h, w, generator=g)
+    dy = torch.randn(2, *out, generator=g)
+    xr = x.clone().requires_grad_(True)
+    ref = F.interpolate(xr[:, None], size=out, mode="trilinear", align_corners=align_corners)[:, 0]
+    ref.backward(dy)
+    y = ops.trilinear_fwd(x.to(dev()), out, align_corners)
+    dx = ops.trilinear_bwd(dy.to(dev()), (d, h, w), align_corners)
+    assert (y.cpu() - ref.detach()).abs().max().item() < 1e-5
+    assert (dx.cpu() - xr.grad).abs().max().item() < 1e-4 * max(1.0, xr.grad.abs().max().item())
+
+
+@pytest.mark.timeout(600)
+def test_progressive_trainer_stage_steps(tmp_path):
+    """One optimisation step of stage 1 and of stage 2 through train_progressive_4gpu.build_stage / train_step: stage 2
+    loads the stage-1 checkpoint, freezes stage 1 (no gradients, weights untouched) and updates stage 2 + its X-ray heads."""
+    import copy, json, os, sys
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(here, "hybrid-vit-cascade_amd", "direct_regression"))
+    from progressive_cascade import train_progressive_4gpu as T
+    from hvc import synthetic
+    cfg = json.load(open(os.path.join(here, "hybrid-vit-cascade_amd", "direct_regression", "progressive_cascade", "config_progressive.json")))
+    torch.manual_seed(0)
+    xr, ct = synthetic.batch(0, 1, (128, 128, 128), 512)
+    xr, ct = xr.to(dev()), ct.to(dev())
+    model, crit, opt, _ = T.build_stage(cfg, 1, tmp_path, dev())
+    model.train()
+    before = copy.deepcopy(model.stage1.state_dict())
+    losses = T.train_step(model, crit, opt, None, xr, ct, 1, cfg["training"]["gradient_clip"])
+    assert set(losses) == {"total_loss", "l1_loss", "ssim_loss"} and torch.isfinite(losses["total_loss"])
+    assert any(not torch.equal(v, before[k]) for k, v in model.stage1.state_dict().items() if v.dtype.is_floating_point)
+    torch.save({"model_state_dict": model.state_dict()}, tmp_path / "stage1_best.pth")
+    s1 = copy.deepcopy(model.stage1.state_dict())
+    model2, crit2, opt2, _ = T.build_stage(cfg, 2, tmp_path, dev())
+    model2.train()
+    for k, v in model2.stage1.state_dict().items():
+        assert torch.equal(v, s1[k]), k                                    # stage-1 checkpoint loaded
+    assert all(not p.requires_grad for p in model2.stage1.parameters())
+    w0 = model2.stage2.vit_refiner.blocks[0].mlp[0].weight.detach().clone()
+    losses = T.train_step(model2, crit2, opt2, None, xr, ct, 2, cfg["training"]["gradient_clip"])
+    assert {"total_loss", "l1_loss", "ssim_loss", "tv_loss", "freq_loss"} <= set(losses) and torch.isfinite(losses["total_loss"])
+    assert all(p.grad is None for p in model2.stage1.parameters())
+    bn_free = {k: v for k, v in model2.stage1.state_dict().items() if "running_" not in k and "num_batches" not in k}
+    for k, v in bn_free.items():
+        assert torch.equal(v, s1[k]), k                                    # frozen weights untouched
+    assert not torch.equal(model2.stage2.vit_refiner.blocks[0].mlp[0].weight.detach(), w0)
+    val = T.validate(model2, [{"drr_stacked": xr.cpu(), "ct_volume": ct.cpu()}], crit2, 0, 2, max_stage=2)
+    assert {"total", "psnr", "ssim"} <= set(val) and val["psnr"] == val["psnr"]
+
+
 def _ddp_gpu_worker(rank, world, port, out_dir):
     import os
     import sys
