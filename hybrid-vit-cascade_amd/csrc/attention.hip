@@ -303,16 +303,19 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 3 : 2) void attn_fwd_kernel(c
 #pragma unroll
                 for (int i = 0; i < 16; ++i) st[kt][i] -= shift;
         }
-        float rs = 0.f;
+        // row sum in register pairs (packed fp32 adds issue at the rate of plain ones), four independent chains
+        f32x2 rs2[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const float p = __builtin_amdgcn_exp2f(st[kt][i]);
-                rs += p;
-                st[kt][i] = p;
+            for (int i = 0; i < 16; i += 2) {
+                const f32x2 p2 = {__builtin_amdgcn_exp2f(st[kt][i]), __builtin_amdgcn_exp2f(st[kt][i + 1])};
+                rs2[(i >> 1) & 3] += p2;
+                st[kt][i] = p2[0];
+                st[kt][i + 1] = p2[1];
             }
-        l += rs;
+        const f32x2 rsum = (rs2[0] + rs2[1]) + (rs2[2] + rs2[3]);
+        l += rsum[0] + rsum[1];
         // O^T[d][q] += V^T P^T
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
@@ -512,11 +515,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
                 bool keep[4] = {true, true, true, true};
                 if constexpr (DROP) drop_keep4(rowkey, key, ts, keep);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float p = __builtin_amdgcn_exp2f(st[kt][i + j]);
-                    if constexpr (MASK) { if (key + j >= a.Nk) p = 0.f; }
-                    const float d = keep[j] ? dpt[kt][i + j] : ndelta;      // keep * dP - delta
-                    st[kt][i + j] = p * d;
+                for (int j = 0; j < 4; j += 2) {
+                    f32x2 p2 = {__builtin_amdgcn_exp2f(st[kt][i + j]), __builtin_amdgcn_exp2f(st[kt][i + j + 1])};
+                    if constexpr (MASK) {
+                        if (key + j >= a.Nk) p2[0] = 0.f;
+                        if (key + j + 1 >= a.Nk) p2[1] = 0.f;
+                    }
+                    const f32x2 d2 = {keep[j] ? dpt[kt][i + j] : ndelta, keep[j + 1] ? dpt[kt][i + j + 1] : ndelta};   // keep * dP - delta
+                    const f32x2 r2 = p2 * d2;
+                    st[kt][i + j] = r2[0];
+                    st[kt][i + j + 1] = r2[1];
                 }
             }
         // dQ[q][d] += dS K  (dS^T accumulators as the A operand, K through the transposed read)
@@ -699,19 +707,24 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a) 
             for (int g = 0; g < 4; ++g) {
                 const int ro = 32 * qt + 8 * g + 4 * h;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < 4; j += 2) {
                     const int i = 4 * g + j;
-                    const float p = __builtin_amdgcn_exp2f(s[i]);
-                    float dpv = dp[i];
-                    float pdv = p;
+                    const f32x2 p2 = {__builtin_amdgcn_exp2f(s[i]), __builtin_amdgcn_exp2f(s[i + 1])};
+                    f32x2 dp2 = {dp[i], dp[i + 1]};
+                    f32x2 pd2 = p2;
                     if constexpr (DROP) {   // 1/(1-p) is folded into delta (pre-divided) and the epilogue scales
-                        const bool keep = (int16_t)lots[((size_t)buf * kKT + ro + j) * kQB + kcol] >= (int16_t)ts;
-                        pdv = keep ? p : 0.f;
-                        dpv = keep ? dpv : nd[i];
-                        asm("" : "+v"(pdv));     // select in fp32, so that the bf16 conversions below stay packed pairs
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            const bool keep = (int16_t)lots[((size_t)buf * kKT + ro + j + e) * kQB + kcol] >= (int16_t)ts;
+                            float pdv = keep ? p2[e] : 0.f;
+                            asm("" : "+v"(pdv));     // select in fp32, so that the bf16 conversions below stay packed pairs
+                            pd2[e] = pdv;
+                            dp2[e] = keep ? dp2[e] : nd[i + e];
+                        }
                     }
-                    pd[i] = pdv;
-                    ds[i] = p * dpv;
+                    const f32x2 ds2 = p2 * dp2;      // packed multiply
+                    pd[i] = pd2[0]; pd[i + 1] = pd2[1];
+                    ds[i] = ds2[0]; ds[i + 1] = ds2[1];
                 }
             }
 #pragma unroll

@@ -24,7 +24,18 @@ KERNEL(k_bitop3, "v_bitop3_b32 %0, %0, %4, %5 bitop3:0x48\n v_bitop3_b32 %1, %1,
 KERNEL(k_perm, "v_perm_b32 %0, %0, %4, %5\n v_perm_b32 %1, %1, %4, %5\n v_perm_b32 %2, %2, %4, %5\n v_perm_b32 %3, %3, %4, %5")
 KERNEL(k_pk_sub_i16, "v_pk_sub_i16 %0, %4, %0\n v_pk_sub_i16 %1, %4, %1\n v_pk_sub_i16 %2, %4, %2\n v_pk_sub_i16 %3, %4, %3")
 KERNEL(k_pk_ashr_i16, "v_pk_ashrrev_i16 %0, 15, %0\n v_pk_ashrrev_i16 %1, 15, %1\n v_pk_ashrrev_i16 %2, 15, %2\n v_pk_ashrrev_i16 %3, 15, %3")
-KERNEL(k_pk_fma_f32_pair, "v_add_f32 %0, %0, %4\n v_add_f32 %1, %1, %4\n v_add_f32 %2, %2, %4\n v_add_f32 %3, %3, %4")
+// packed fp32: each instruction works on a register pair (2 values / lane)
+#define KERNEL2(name, INS)                                                             \
+    __global__ __launch_bounds__(64) void name(uint32_t* out, int iters, uint32_t b, uint32_t c) { \
+        typedef float f2 __attribute__((ext_vector_type(2)));                          \
+        f2 a0 = {1.f * threadIdx.x, 2.f}, a1 = a0 + 1.f, a2 = a0 + 2.f, a3 = a0 + 3.f, bb = {1.0001f, 0.9999f}; \
+        for (int i = 0; i < iters; ++i) { REP8(REP8(asm volatile(INS : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(bb));)) } \
+        out[blockIdx.x * 64 + threadIdx.x] = (uint32_t)(a0.x + a1.y + a2.x + a3.y);   \
+    }
+KERNEL2(k_pk_mul_f32, "v_pk_mul_f32 %0, %0, %4\n v_pk_mul_f32 %1, %1, %4\n v_pk_mul_f32 %2, %2, %4\n v_pk_mul_f32 %3, %3, %4")
+KERNEL2(k_pk_add_f32, "v_pk_add_f32 %0, %0, %4\n v_pk_add_f32 %1, %1, %4\n v_pk_add_f32 %2, %2, %4\n v_pk_add_f32 %3, %3, %4")
+KERNEL2(k_pk_fma_f32, "v_pk_fma_f32 %0, %0, %4, %4\n v_pk_fma_f32 %1, %1, %4, %4\n v_pk_fma_f32 %2, %2, %4, %4\n v_pk_fma_f32 %3, %3, %4, %4")
+KERNEL2(k_mov_b64, "v_mov_b64 %0, %4\n v_mov_b64 %1, %4\n v_mov_b64 %2, %4\n v_mov_b64 %3, %4")
 KERNEL(k_cmp_cnd, "v_cmp_le_u32 vcc, %5, %0\n v_cndmask_b32 %1, 0, %1, vcc\n v_cmp_le_u32 vcc, %5, %2\n v_cndmask_b32 %3, 0, %3, vcc")
 KERNEL(k_cmp_sdwa_cnd, "v_cmp_ge_u32_sdwa vcc, %0, %5 src0_sel:WORD_1 src1_sel:DWORD\n v_cndmask_b32 %1, 0, %1, vcc\n v_cmp_ge_u32_sdwa vcc, %2, %5 src0_sel:WORD_1 src1_sel:DWORD\n v_cndmask_b32 %3, 0, %3, vcc")
 KERNEL(k_max3, "v_max3_f32 %0, %0, %4, %1\n v_max3_f32 %1, %1, %4, %2\n v_max3_f32 %2, %2, %4, %3\n v_max3_f32 %3, %3, %4, %0")
@@ -55,6 +66,6 @@ int main() {
     float base = run(k_add_f32, "v_add_f32", out, 0);
 #define R(k) run(k, #k, out, base)
     R(k_fma_f32); R(k_mul_lo); R(k_mul_hi); R(k_mul_u24); R(k_mad_u24); R(k_exp); R(k_cvt_pk); R(k_xor); R(k_xor_sdwa); R(k_bitop3); R(k_perm);
-    R(k_pk_sub_i16); R(k_pk_ashr_i16); R(k_cmp_cnd); R(k_cmp_sdwa_cnd); R(k_max3); R(k_lshr); R(k_and_or);
+    R(k_pk_sub_i16); R(k_pk_ashr_i16); R(k_pk_mul_f32); R(k_pk_add_f32); R(k_pk_fma_f32); R(k_mov_b64); R(k_cmp_cnd); R(k_cmp_sdwa_cnd); R(k_max3); R(k_lshr); R(k_and_or);
     return 0;
 }
