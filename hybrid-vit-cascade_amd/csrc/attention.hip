@@ -34,6 +34,10 @@ namespace {
 
 constexpr int kKT = 64;     // keys (or queries, in dKV) per LDS tile
 constexpr int kQB = 128;    // rows per workgroup
+// Row stride (in 16-bit lots) of the dK/dV kernel's dropout-lot tile: 128 keys + 8 of padding = 272 bytes, so that
+// the 16 query rows a wavefront writes with ds_write_b128 land on 16 distinct 4-bank groups, and the rows q and q+4
+// read by the two lane halves of a wavefront land on disjoint banks (rocprofv3: SQ_LDS_BANK_CONFLICT 402 M -> 0).
+constexpr int kLotStride = kQB + 8;
 constexpr float kRescaleLog2 = 6.f;   // deferred running-max update: P stays <= 2^6 between rescales
 
 // 8 elements of row n (zeros when n >= nrows).  VEC: one clamped 16-byte load + select (no branch).
@@ -580,7 +584,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a) 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16* lds = reinterpret_cast<bf16*>(smem);                       // [buf][Q|dO][NS][TILE]
     float* stat = reinterpret_cast<float*>(lds + 4 * NS * TILE);     // [buf][lse2|delta][kKT]
-    // [buf][64 q][128 keys] 16-bit dropout lots of the current q-tile x this workgroup's keys, generated cooperatively
+    // [buf][64 q][kLotStride] 16-bit dropout lots of the current q-tile x this workgroup's 128 keys, generated cooperatively
     // (one hash per 4 keys, as in the forward) so that the per-element cost is a 2-byte LDS read + compare + selects.
     uint16_t* lots = reinterpret_cast<uint16_t*>(stat + 2 * 2 * kKT);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -640,7 +644,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a) 
             const int q = min(t * kKT + ql, a.Nq - 1);
             const uint32_t rk = drop_rowkey(a, bh, q);
             const int key0 = kb * kQB + 32 * part;
-            uint32_t* dst = reinterpret_cast<uint32_t*>(lots + ((size_t)buf * kKT + ql) * kQB + 32 * part);
+            uint32_t* dst = reinterpret_cast<uint32_t*>(lots + ((size_t)buf * kKT + ql) * kLotStride + 32 * part);
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const uint32_t m = drop_mix(rk, (uint32_t)((key0 + 4 * u) >> 2) * kKeyMul);
@@ -715,7 +719,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a) 
                     if constexpr (DROP) {   // 1/(1-p) is folded into delta (pre-divided) and the epilogue scales
 #pragma unroll
                         for (int e = 0; e < 2; ++e) {
-                            const bool keep = (int16_t)lots[((size_t)buf * kKT + ro + j + e) * kQB + kcol] >= (int16_t)ts;
+                            const bool keep = (int16_t)lots[((size_t)buf * kKT + ro + j + e) * kLotStride + kcol] >= (int16_t)ts;
                             float pdv = keep ? p2[e] : 0.f;
                             asm("" : "+v"(pdv));     // select in fp32, so that the bf16 conversions below stay packed pairs
                             pd2[e] = pdv;
@@ -811,7 +815,7 @@ __global__ __launch_bounds__(256) void attn_dkv_reduce_kernel(const AttnArgs a) 
 template <typename T, int D>
 size_t fwd_lds_bytes() { return (size_t)2 * 2 * NSplit<T>::value * kKT * D * sizeof(bf16); }
 template <typename T, int D>
-size_t dkv_lds_bytes(bool drop) { return fwd_lds_bytes<T, D>() + 2 * 2 * kKT * sizeof(float) + (drop ? 2 * kKT * kQB * sizeof(uint16_t) : 0); }
+size_t dkv_lds_bytes(bool drop) { return fwd_lds_bytes<T, D>() + 2 * 2 * kKT * sizeof(float) + (drop ? 2 * kKT * kLotStride * sizeof(uint16_t) : 0); }
 
 template <typename K>
 hipError_t set_lds(K kernel, size_t bytes) {

@@ -23,10 +23,6 @@ namespace {
 
 constexpr int kBM = 128, kBN = 128;
 
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
-__device__ __forceinline__ float gelu_grad_f(float x) {
-    return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
-}
 
 // n (<= 8) consecutive elements <-> 8 floats; vec: one 16-byte (bf16) / two 16-byte (fp32) accesses.
 template <typename T>
@@ -271,14 +267,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] *= gelu_grad_f(rpre[it][e]);
         }
-        if (g.drop_thresh) {
-            const uint64_t e0 = (uint64_t)i * (uint64_t)g.N + (uint64_t)j;     // even when vec (N, j multiples of 8)
+        if (g.drop_thresh) {      // j is a multiple of 8: two 4-column hash groups per row segment
+            bool keep[8];
+            drop2d_keep8(drop2d_rowkey(g.seed_lo, g.seed_hi, (uint64_t)i), (uint32_t)j, g.drop_thresh, keep);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const uint64_t el = e0 + e;
-                const uint32_t bits = rng_pair(g.seed_lo, g.seed_hi, (uint32_t)(el >> 1), (uint32_t)(el >> 33));
-                v[e] = (((bits >> (16 * (el & 1))) & 0xffffu) >= g.drop_thresh) ? v[e] * g.keep_scale : 0.f;
-            }
+            for (int e = 0; e < 8; ++e) v[e] = keep[e] ? v[e] * g.keep_scale : 0.f;
         }
         if (zp) store_n<TI>(zp + (int64_t)i * g.ldz + j, v, nj, vec);
         if (g.gate) {

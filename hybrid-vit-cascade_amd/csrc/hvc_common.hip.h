@@ -189,6 +189,64 @@ __device__ __forceinline__ uint32_t rng_pair(uint32_t seed_lo, uint32_t seed_hi,
     return mix32(mix32(idx_lo ^ seed_lo) + (idx_hi ^ seed_hi) * 0x9E3779B9U);
 }
 
+// Dropout of a row-major (rows x cols) activation (GEMM-epilogue dropouts and their backward): one well-mixed
+// 32-bit key per row, then one multiply-xorshift round per 4 consecutive columns yielding four 16-bit lots
+// (element kept when lot >= thresh).  ~3 instructions / element when a thread owns 8 consecutive columns,
+// against ~20 for a full hash per element.
+constexpr uint32_t kDropKeyMul = 0x85EBCA6Bu, kDropLotMulA = 0x7feb352dU, kDropLotMulB = 0x846ca68bU;
+__device__ __forceinline__ uint32_t drop2d_rowkey(uint32_t seed_lo, uint32_t seed_hi, uint64_t row) {
+    return mix32(((uint32_t)row * 0x9E3779B1u) ^ ((uint32_t)(row >> 32) * 0xC2B2AE35u) ^ seed_lo) ^ seed_hi;
+}
+// lots of columns 4*col4 .. 4*col4+3: wa = {c0 (low half), c1}, wb = {c2, c3}
+__device__ __forceinline__ void drop2d_lots4(uint32_t rowkey, uint32_t col4, uint32_t& wa, uint32_t& wb) {
+    uint32_t x = rowkey + col4 * kDropKeyMul;
+    x ^= x >> 16;
+    wa = x * kDropLotMulA; wa ^= wa >> 15;
+    wb = x * kDropLotMulB; wb ^= wb >> 15;
+}
+__device__ __forceinline__ bool drop2d_keep(uint32_t rowkey, uint32_t col, uint32_t thresh) {   // single element (ragged paths)
+    uint32_t wa, wb;
+    drop2d_lots4(rowkey, col >> 2, wa, wb);
+    const uint32_t w = (col & 2) ? wb : wa;
+    return ((w >> (16 * (col & 1))) & 0xffffu) >= thresh;
+}
+// keep flags of 8 consecutive columns starting at col (col % 8 == 0... any multiple of 4)
+__device__ __forceinline__ void drop2d_keep8(uint32_t rowkey, uint32_t col, uint32_t thresh, bool (&keep)[8]) {
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        uint32_t wa, wb;
+        drop2d_lots4(rowkey, (col >> 2) + g, wa, wb);
+        keep[4 * g + 0] = (wa & 0xffffu) >= thresh; keep[4 * g + 1] = (wa >> 16) >= thresh;
+        keep[4 * g + 2] = (wb & 0xffffu) >= thresh; keep[4 * g + 3] = (wb >> 16) >= thresh;
+    }
+}
+
+// Exact-GELU pieces (reference: nn.GELU() = x * Phi(x), erf form).  Phi through Abramowitz-Stegun 7.1.26
+// (|erf error| <= 1.5e-7, i.e. fp32 rounding level): one v_rcp, one v_exp and a degree-5 Horner, no branches;
+// exp(-x^2/2) is shared with the density phi(x) needed by the derivative.  ~15 issue slots against ~35 for erff().
+__device__ __forceinline__ void gelu_parts(float x, float& Phi, float& phi) {
+    const float z = fabsf(x) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.f));
+    const float e = __builtin_amdgcn_exp2f(-0.72134752044448170f * x * x);        // exp(-x^2 / 2)
+    float poly = fmaf(t, 1.061405429f, -1.453152027f);
+    poly = fmaf(t, poly, 1.421413741f);
+    poly = fmaf(t, poly, -0.284496736f);
+    poly = fmaf(t, poly, 0.254829592f);
+    const float half_erfc = 0.5f * t * poly * e;                                    // 0.5 * erfc(|x| / sqrt 2)
+    Phi = x >= 0.f ? 1.f - half_erfc : half_erfc;
+    phi = 0.3989422804014327f * e;
+}
+__device__ __forceinline__ float gelu_f(float x) {
+    float Phi, phi;
+    gelu_parts(x, Phi, phi);
+    return x * Phi;
+}
+__device__ __forceinline__ float gelu_grad_f(float x) {
+    float Phi, phi;
+    gelu_parts(x, Phi, phi);
+    return fmaf(x, phi, Phi);
+}
+
 // wave-level sum over all 64 lanes
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

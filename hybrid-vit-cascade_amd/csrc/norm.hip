@@ -174,10 +174,10 @@ __device__ __forceinline__ float silu_grad_f(float z) {
 }
 // act: 0 = SiLU (voxel-embed stem), 1 = GELU(erf) (cascade glue: model_progressive.py:37-51, 169-174)
 __device__ __forceinline__ float act_f(float z, int act) {
-    return act == 0 ? silu_f(z) : 0.5f * z * (1.f + erff(z * 0.70710678118654752f));
+    return act == 0 ? silu_f(z) : gelu_f(z);
 }
 __device__ __forceinline__ float act_grad_f(float z, int act) {
-    return act == 0 ? silu_grad_f(z) : 0.5f * (1.f + erff(z * 0.70710678118654752f)) + z * 0.3989422804014327f * __expf(-0.5f * z * z);
+    return act == 0 ? silu_grad_f(z) : gelu_grad_f(z);
 }
 
 // ---- GroupNorm + SiLU apply ---------------------------------------------------------------------------

@@ -76,12 +76,10 @@ __global__ __launch_bounds__(256) void branch_bwd_kernel(const BranchArgs a) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] = d[j] * gt[j];
                 if (a.drop_thresh) {
+                    bool keep[8];
+                    drop2d_keep8(drop2d_rowkey(a.seed_lo, a.seed_hi, (uint64_t)bidx * rpb + rr), (uint32_t)(c8 * 8), a.drop_thresh, keep);
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const uint64_t el = (uint64_t)e + j;
-                        const uint32_t bits = rng_pair(a.seed_lo, a.seed_hi, (uint32_t)(el >> 1), (uint32_t)(el >> 33));
-                        v[j] = (((bits >> (16 * (el & 1))) & 0xffffu) >= a.drop_thresh) ? v[j] * a.keep_scale : 0.f;
-                    }
+                    for (int j = 0; j < 8; ++j) v[j] = keep[j] ? v[j] * a.keep_scale : 0.f;
                 }
                 if (z) {
                     float zz[8];
@@ -104,10 +102,8 @@ __global__ __launch_bounds__(256) void branch_bwd_kernel(const BranchArgs a) {
                 const int64_t e = ((int64_t)bidx * rpb + rr) * a.N + c;
                 const float d = a.dy[e];
                 float v = d * gt;
-                if (a.drop_thresh) {
-                    const uint32_t bits = rng_pair(a.seed_lo, a.seed_hi, (uint32_t)((uint64_t)e >> 1), (uint32_t)((uint64_t)e >> 33));
-                    v = (((bits >> (16 * (e & 1))) & 0xffffu) >= a.drop_thresh) ? v * a.keep_scale : 0.f;
-                }
+                if (a.drop_thresh)
+                    v = drop2d_keep(drop2d_rowkey(a.seed_lo, a.seed_hi, (uint64_t)bidx * rpb + rr), (uint32_t)c, a.drop_thresh) ? v * a.keep_scale : 0.f;
                 if (z) sg += d * to_f<TO>(z[e]);
                 sb += v;
                 dz[e] = from_f<TO>(v);
