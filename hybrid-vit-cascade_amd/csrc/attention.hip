@@ -307,19 +307,16 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 3 : 2) void attn_fwd_kernel(c
 #pragma unroll
                 for (int i = 0; i < 16; ++i) st[kt][i] -= shift;
         }
-        // row sum in register pairs (packed fp32 adds issue at the rate of plain ones), four independent chains
-        f32x2 rs2[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+        float rs = 0.f;      // plain adds: the packed form (v_pk_add_f32) measured 2-6 % slower here, its dependent chain needs wait states
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-            for (int i = 0; i < 16; i += 2) {
-                const f32x2 p2 = {__builtin_amdgcn_exp2f(st[kt][i]), __builtin_amdgcn_exp2f(st[kt][i + 1])};
-                rs2[(i >> 1) & 3] += p2;
-                st[kt][i] = p2[0];
-                st[kt][i + 1] = p2[1];
+            for (int i = 0; i < 16; ++i) {
+                const float p = __builtin_amdgcn_exp2f(st[kt][i]);
+                rs += p;
+                st[kt][i] = p;
             }
-        const f32x2 rsum = (rs2[0] + rs2[1]) + (rs2[2] + rs2[3]);
-        l += rsum[0] + rsum[1];
+        l += rs;
         // O^T[d][q] += V^T P^T
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {

@@ -118,17 +118,25 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
     const int wm = wave >> 1, wn = wave & 1;
     const int r = lane & 31, h = lane >> 5;
 
-    // XCD-aware tile order: workgroups that share an XCD (id % 8) walk neighbouring row panels
-    // of one column panel, so the B (weight) panel and A row panels stay in that XCD's L2.
+    // XCD-aware work order.  Workgroup b runs on XCD b % 8 (round-robin dispatch), so XCD x is given the
+    // contiguous chunk x of the work list and walks it in launch order.  The list is ordered so that neighbours
+    // share operand panels through that XCD's L2: the tiles of one split-K slice are adjacent (they read the same
+    // K-slice of both operands), and inside a slice the shorter tile dimension runs fastest, so a panel of the
+    // LARGE operand (e.g. 128 activation rows x K) is used by all its column tiles back to back while the
+    // small operand (weights) stays L2-resident anyway.
     const int tiles_m = (g.M + kBM - 1) / kBM, tiles_n = (g.N + kBN - 1) / kBN;
     const int nwg = tiles_m * tiles_n;
-    const int split = blockIdx.x / nwg;      // split-K slice (0 when splitk == 1)
-    int id = blockIdx.x % nwg;
+    int w = blockIdx.x;
     {
-        const int q = nwg >> 3, rem = nwg & 7, xcd = id & 7, slot = id >> 3;
-        id = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + slot;
+        const int total = nwg * g.splitk;
+        const int q = total >> 3, rem = total & 7, xcd = w & 7, slot = w >> 3;
+        w = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + slot;
     }
-    const int tm = id % tiles_m, tn = id / tiles_m;
+    const int split = w / nwg;               // split-K slice (0 when splitk == 1)
+    const int id = w % nwg;
+    int tm, tn;
+    if (tiles_m >= tiles_n) { tn = id % tiles_n; tm = id / tiles_n; }
+    else { tm = id % tiles_m; tn = id / tiles_m; }
     const int i0 = tm * kBM, j0 = tn * kBN;
 
     const TI* Ap = reinterpret_cast<const TI*>(g.A);
