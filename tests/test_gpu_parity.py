@@ -536,6 +536,36 @@ def test_cascade_refiners_vs_golden(golden, mode):
             g.check(f"{pre}_pgrad", k, p.grad, max(tol, 3e-3), 10, metric="l2")    # ReLU / max-pool routing upstream: norm metric
 
 
+def test_stage3_gradient_checkpointing_replays_dropout_masks():
+    """BASELINE config #5 trains stage 3 with gradient checkpointing (model_progressive.py:296-305).  The recomputation
+    must redraw the same counter-based dropout seeds (torch.utils.checkpoint restores the CPU generator they come
+    from): gradients with and without checkpointing are then bitwise equal in train mode with dropout 0.1."""
+    from direct_regression.progressive_cascade.model_progressive import Stage3Refiner256
+    torch.manual_seed(5)
+    ref = Stage3Refiner256(volume_size=(32, 32, 32), voxel_dim=64, vit_depth=2, num_heads=2, xray_feature_dim=32,
+                           use_gradient_checkpointing=False).to(dev()).train()
+    for blk in ref.vit_refiner.blocks:                      # AdaLN is zero-initialised: give the gated branches some weight
+        torch.nn.init.normal_(blk.adaln.linear.weight, std=0.02)
+    ck = Stage3Refiner256(volume_size=(32, 32, 32), voxel_dim=64, vit_depth=2, num_heads=2, xray_feature_dim=32,
+                          use_gradient_checkpointing=True).to(dev()).train()
+    ck.load_state_dict(ref.state_dict())
+    g = torch.Generator().manual_seed(6)
+    v = torch.randn(1, 1, 16, 16, 16, generator=g).to(dev())
+    feats = torch.randn(1, 32, 8, 8, generator=g).to(dev())
+    cond = torch.randn(1, 1024, generator=g).to(dev())
+    outs = []
+    for m in (ref, ck):
+        torch.manual_seed(77)                               # same dropout seed stream for both runs
+        vin = v.clone().requires_grad_(True)
+        out = m(vin, feats, cond)
+        out.square().mean().backward()
+        outs.append((out.detach(), vin.grad, {k: p.grad for k, p in m.named_parameters() if p.grad is not None}))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert outs[0][2].keys() == outs[1][2].keys() and len(outs[0][2]) > 20
+    for k in outs[0][2]:
+        assert torch.equal(outs[0][2][k], outs[1][2][k]), k
+
+
 def test_drr_reprojection_loss_vs_golden(golden):
     from direct_regression.progressive_cascade.loss_multiscale import DRRReprojectionLoss, compute_psnr
     g = golden("drr")
