@@ -260,17 +260,25 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 // Second stage of the deterministic two-stage column reductions: sum partial[r * stride + c] over
-// r in [0, nrows) for column c = 32 * blockIdx.x + (tid & 31).  256 threads = 32 columns x 8 row
-// groups; fixed summation order.  Returns the sum in the threads with (tid >> 5) == 0.
-__device__ __forceinline__ float block_colsum32(const float* __restrict__ partial, int nrows, int64_t stride, int c, bool valid,
-                                                float (*red)[32]) {
-    const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+// r in [0, nrows) for column c = 8 * blockIdx.x + (tid & 7).  256 threads = 8 columns x 32 row
+// groups (a few hundred partial rows are typical: 32-way row parallelism keeps the load chain at ~16
+// steps, with 4x more workgroups than a 32-column block); fixed summation order.
+// Returns the sum in the threads with (tid >> 3) == 0.
+constexpr int kFinalCols = 8;
+__device__ __forceinline__ float block_colsum8(const float* __restrict__ partial, int nrows, int64_t stride, int c, bool valid,
+                                               float (*red)[kFinalCols]) {
+    const int cl = threadIdx.x & 7, rg = threadIdx.x >> 3;
     float s = 0.f;
     if (valid)
-        for (int r = rg; r < nrows; r += 8) s += partial[(int64_t)r * stride + c];
+        for (int r = rg; r < nrows; r += 32) s += partial[(int64_t)r * stride + c];
     red[rg][cl] = s;
     __syncthreads();
-    return ((red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl])) + ((red[4][cl] + red[5][cl]) + (red[6][cl] + red[7][cl]));
+    float t = 0.f;
+    if (rg == 0) {
+#pragma unroll
+        for (int k = 0; k < 32; k += 4) t += (red[k][cl] + red[k + 1][cl]) + (red[k + 2][cl] + red[k + 3][cl]);
+    }
+    return t;
 }
 
 template <typename T> __device__ __forceinline__ float to_f(T x);

@@ -180,24 +180,24 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnArgs a) {
         out[i] = ((red[i] + red[4 * C + i]) + red[8 * C + i]) + red[12 * C + i];
 }
 
-// grid (ceil(C/32), 2 + 2*nbatch): y = 0 dgamma, 1 dbeta (over all blocks); y = 2 + 2b + k: dscale / dshift of sample b.
+// grid (ceil(C/8), 2 + 2*nbatch): y = 0 dgamma, 1 dbeta (over all blocks); y = 2 + 2b + k: dscale / dshift of sample b.
 __global__ __launch_bounds__(256) void ln_bwd_final_kernel(const LnArgs a, int nbatch) {
-    __shared__ float red[8][32];
+    __shared__ float red[32][kFinalCols];
     const int C = a.C, bpb = a.blocks_per_batch;
-    const int c = 32 * blockIdx.x + (threadIdx.x & 31);
+    const int c = kFinalCols * blockIdx.x + (threadIdx.x & 7);
     const bool valid = c < C;
     const int y = blockIdx.y;
     float* dst;
     float s;
     if (y < 2) {
-        s = block_colsum32(a.partial + (size_t)y * C, nbatch * bpb, 4 * (int64_t)C, c, valid, red);
+        s = block_colsum8(a.partial + (size_t)y * C, nbatch * bpb, 4 * (int64_t)C, c, valid, red);
         dst = (y == 0 ? a.dgamma : a.dbeta) + c;
     } else {
         const int b = (y - 2) >> 1, k = (y - 2) & 1;
-        s = block_colsum32(a.partial + ((size_t)b * bpb * 4 + 2 + k) * C, bpb, 4 * (int64_t)C, c, valid, red);
+        s = block_colsum8(a.partial + ((size_t)b * bpb * 4 + 2 + k) * C, bpb, 4 * (int64_t)C, c, valid, red);
         dst = (k == 0 ? a.dscale : a.dshift) + (size_t)b * C + c;
     }
-    if (valid && (threadIdx.x >> 5) == 0) *dst = s;
+    if (valid && (threadIdx.x >> 3) == 0) *dst = s;
 }
 
 }  // namespace
@@ -241,7 +241,7 @@ hipError_t layernorm_bwd_launch(const LnArgs& a, hipStream_t st) {
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(ln_bwd_final_kernel, dim3((a.C + 31) / 32, 2 + (a.dscale ? 2 * nbatch : 0)), blk, 0, st, a, nbatch);
+    hipLaunchKernelGGL(ln_bwd_final_kernel, dim3((a.C + kFinalCols - 1) / kFinalCols, 2 + (a.dscale ? 2 * nbatch : 0)), blk, 0, st, a, nbatch);
     return hipGetLastError();
 }
 

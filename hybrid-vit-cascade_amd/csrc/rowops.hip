@@ -114,21 +114,21 @@ __global__ __launch_bounds__(256) void branch_bwd_kernel(const BranchArgs a) {
     }
 }
 
-// grid (ceil(N/32), 1 + nbatch): y = 0 dbias over all blocks; y = 1 + b: dgate of sample b.
+// grid (ceil(N/8), 1 + nbatch): y = 0 dbias over all blocks; y = 1 + b: dgate of sample b.
 __global__ __launch_bounds__(256) void branch_final_kernel(const BranchArgs a, int nbatch) {
-    __shared__ float red[8][32];
+    __shared__ float red[32][kFinalCols];
     const int N = a.N, bpb = a.blocks_per_batch;
-    const int c = 32 * blockIdx.x + (threadIdx.x & 31);
+    const int c = kFinalCols * blockIdx.x + (threadIdx.x & 7);
     const bool valid = c < N;
     if (blockIdx.y == 0) {
         if (!a.dbias) return;
-        const float s = block_colsum32(a.partial + N, nbatch * bpb, 2 * (int64_t)N, c, valid, red);
-        if (valid && (threadIdx.x >> 5) == 0) a.dbias[c] = s;
+        const float s = block_colsum8(a.partial + N, nbatch * bpb, 2 * (int64_t)N, c, valid, red);
+        if (valid && (threadIdx.x >> 3) == 0) a.dbias[c] = s;
     } else {
         if (!a.dgate) return;
         const int b = blockIdx.y - 1;
-        const float s = block_colsum32(a.partial + (size_t)b * bpb * 2 * N, bpb, 2 * (int64_t)N, c, valid, red);
-        if (valid && (threadIdx.x >> 5) == 0) a.dgate[(size_t)b * N + c] = s;
+        const float s = block_colsum8(a.partial + (size_t)b * bpb * 2 * N, bpb, 2 * (int64_t)N, c, valid, red);
+        if (valid && (threadIdx.x >> 3) == 0) a.dgate[(size_t)b * N + c] = s;
     }
 }
 
@@ -164,10 +164,10 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* x, float* partial,
     }
 }
 __global__ __launch_bounds__(256) void colsum_final_kernel(const float* partial, float* out, int N, int nblk) {
-    __shared__ float red[8][32];
-    const int c = 32 * blockIdx.x + (threadIdx.x & 31);
-    const float s = block_colsum32(partial, nblk, (int64_t)N, c, c < N, red);
-    if (c < N && (threadIdx.x >> 5) == 0) out[c] = s;
+    __shared__ float red[32][kFinalCols];
+    const int c = kFinalCols * blockIdx.x + (threadIdx.x & 7);
+    const float s = block_colsum8(partial, nblk, (int64_t)N, c, c < N, red);
+    if (c < N && (threadIdx.x >> 3) == 0) out[c] = s;
 }
 
 template <typename TI, typename TO>
@@ -202,7 +202,7 @@ hipError_t branch_bwd_launch(const BranchArgs& a, hipStream_t st) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (!a.dbias && !a.dgate) return hipSuccess;
-    hipLaunchKernelGGL(branch_final_kernel, dim3((a.N + 31) / 32, 1 + (a.dgate ? nbatch : 0)), blk, 0, st, a, nbatch);
+    hipLaunchKernelGGL(branch_final_kernel, dim3((a.N + kFinalCols - 1) / kFinalCols, 1 + (a.dgate ? nbatch : 0)), blk, 0, st, a, nbatch);
     return hipGetLastError();
 }
 
@@ -218,7 +218,7 @@ hipError_t colsum_launch(const void* x, float* partial, float* out, int M, int N
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((N + 31) / 32), dim3(256), 0, st, partial, out, N, nblk);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((N + kFinalCols - 1) / kFinalCols), dim3(256), 0, st, partial, out, N, nblk);
     return hipGetLastError();
 }
 
