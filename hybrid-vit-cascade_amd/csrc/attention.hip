@@ -249,11 +249,26 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 3 : 2) void attn_fwd_kernel(c
     const uint32_t rowkey = DROP ? drop_rowkey(a, bh, qrow_c) : 0u;
     const uint32_t tm1x2 = DROP ? ((uint32_t)(drop_ts(a) - 1) & 0xffffu) * 0x10001u : 0u;
 
+    // Per-lane LDS addresses of the K row fragments (one per 16-wide d step) and the transposed V fragments (two row
+    // groups per 32-wide d block); tile buffer, key sub-tile and split image enter as immediate offsets.
+    const bf16* kaddr[D / 16];
+    const bf16* vaddr[D / 32][2];
+#pragma unroll
+    for (int s = 0; s < D / 16; ++s) kaddr[s] = lds + row_frag_lane_off<D>(16 * s, lane);
+#pragma unroll
+    for (int dt = 0; dt < D / 32; ++dt) {
+        int oa, ob;
+        tr_frag_lane_off<D, true>(32 * dt, lane, oa, ob);
+        vaddr[dt][0] = lds + oa;
+        vaddr[dt][1] = lds + ob;
+    }
+
     // One 64-key tile.  MASK is only instantiated for a ragged last tile, so the full tiles carry no
-    // per-element bounds selects.
-    auto tile = [&](auto mask_tag, int t) {
+    // per-element bounds selects; the LDS buffer index is a compile-time constant (the tile loop is unrolled by two).
+    auto tile = [&](auto mask_tag, auto buf_tag, int t) {
         constexpr bool MASK = decltype(mask_tag)::value;
-        const int buf = t & 1;
+        constexpr int buf = decltype(buf_tag)::value;
+        constexpr int KOFF = (buf * 2 + 0) * NS * TILE, VOFF = (buf * 2 + 1) * NS * TILE;
         if (t + 1 < nt) {
             kl.issue(kp, a.k_sn, (t + 1) * kKT, a.Nk, tid);
             vl.issue(vp, a.v_sn, (t + 1) * kKT, a.Nk, tid);
@@ -267,7 +282,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 3 : 2) void attn_fwd_kernel(c
             for (int s = 0; s < D / 16; ++s) {
 #pragma unroll
                 for (int sa = 0; sa < NS; ++sa) {
-                    bf16x8 kf = row_frag<D>(Kt(buf) + sa * TILE, 32 * kt, 16 * s, lane);
+                    bf16x8 kf = *reinterpret_cast<const bf16x8*>(kaddr[s] + (KOFF + sa * TILE + 32 * kt * D));
 #pragma unroll
                     for (int sb = 0; sb < NS; ++sb)
                         if (sa + sb <= 1) st[kt] = mfma32(kf, qf[sb][s], st[kt]);
@@ -347,7 +362,8 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 3 : 2) void attn_fwd_kernel(c
                 for (int dt = 0; dt < D / 32; ++dt) {
 #pragma unroll
                     for (int sa = 0; sa < NS; ++sa) {
-                        bf16x8 vf = tr_frag<D, true>(Vt(buf) + sa * TILE, 32 * kt + 16 * s2, 32 * dt, lane);
+                        const int VO = VOFF + (32 * kt + 16 * s2) * D;
+                        bf16x8 vf = tr_frag_at(vaddr[dt][0] + (VO + sa * TILE), vaddr[dt][1] + (VO + sa * TILE));
 #pragma unroll
                         for (int sb = 0; sb < NS; ++sb)
                             if (sa + sb <= 1) o[dt] = mfma32(vf, pf[sb], o[dt]);
@@ -363,8 +379,18 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 3 : 2) void attn_fwd_kernel(c
     };
     const bool ragged = (a.Nk % kKT) != 0;
     const int nfull = ragged ? nt - 1 : nt;
-    for (int t = 0; t < nfull; ++t) tile(std::false_type{}, t);
-    if (ragged) tile(std::true_type{}, nt - 1);
+    using B0 = std::integral_constant<int, 0>;
+    using B1 = std::integral_constant<int, 1>;
+    int t = 0;
+    for (; t + 1 < nfull; t += 2) {
+        tile(std::false_type{}, B0{}, t);
+        tile(std::false_type{}, B1{}, t + 1);
+    }
+    if (t < nfull) tile(std::false_type{}, B0{}, t);            // t is even here
+    if (ragged) {
+        if ((nt - 1) & 1) tile(std::true_type{}, B1{}, nt - 1);
+        else tile(std::true_type{}, B0{}, nt - 1);
+    }
 
     const float ltot = l + __shfl_xor(l, 32, 64);
     const float inv = (DROP ? a.keep_scale : 1.f) / ltot;
@@ -479,9 +505,23 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
     const uint32_t rowkey = DROP ? drop_rowkey(a, bh, qrow_c) : 0u;
     const int ts = drop_ts(a);
 
-    auto tile = [&](auto mask_tag, int t) {
+    // per-lane LDS addresses (see the forward kernel): K / V row fragments share one set, K^T fragments another
+    const bf16* raddr[D / 16];
+    const bf16* taddr[D / 32][2];
+#pragma unroll
+    for (int s = 0; s < D / 16; ++s) raddr[s] = lds + row_frag_lane_off<D>(16 * s, lane);
+#pragma unroll
+    for (int dt = 0; dt < D / 32; ++dt) {
+        int oa, ob;
+        tr_frag_lane_off<D, true>(32 * dt, lane, oa, ob);
+        taddr[dt][0] = lds + oa;
+        taddr[dt][1] = lds + ob;
+    }
+
+    auto tile = [&](auto mask_tag, auto buf_tag, int t) {
         constexpr bool MASK = decltype(mask_tag)::value;
-        const int buf = t & 1;
+        constexpr int buf = decltype(buf_tag)::value;
+        constexpr int KOFF = (buf * 2 + 0) * NS * TILE, VOFF = (buf * 2 + 1) * NS * TILE;
         if (t + 1 < nt) {
             kl.issue(kp, a.k_sn, (t + 1) * kKT, a.Nk, tid);
             vl.issue(vp, a.v_sn, (t + 1) * kKT, a.Nk, tid);
@@ -495,8 +535,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
             for (int s = 0; s < D / 16; ++s) {
 #pragma unroll
                 for (int sa = 0; sa < NS; ++sa) {
-                    bf16x8 kf = row_frag<D>(Kt(buf) + sa * TILE, 32 * kt, 16 * s, lane);
-                    bf16x8 vf = row_frag<D>(Vt(buf) + sa * TILE, 32 * kt, 16 * s, lane);
+                    bf16x8 kf = *reinterpret_cast<const bf16x8*>(raddr[s] + (KOFF + sa * TILE + 32 * kt * D));
+                    bf16x8 vf = *reinterpret_cast<const bf16x8*>(raddr[s] + (VOFF + sa * TILE + 32 * kt * D));
 #pragma unroll
                     for (int sb = 0; sb < NS; ++sb)
                         if (sa + sb <= 1) {
@@ -542,7 +582,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
                 for (int dt = 0; dt < D / 32; ++dt) {
 #pragma unroll
                     for (int sb = 0; sb < NS; ++sb) {
-                        bf16x8 kf = tr_frag<D, true>(Kt(buf) + sb * TILE, 32 * kt + 16 * s2, 32 * dt, lane);
+                        const int KO = KOFF + sb * TILE + (32 * kt + 16 * s2) * D;
+                        bf16x8 kf = tr_frag_at(taddr[dt][0] + KO, taddr[dt][1] + KO);
 #pragma unroll
                         for (int sa = 0; sa < NS; ++sa)
                             if (sa + sb <= 1) dq[dt] = mfma32(dsf[sa], kf, dq[dt]);
@@ -558,8 +599,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
     };
     const bool ragged = (a.Nk % kKT) != 0;
     const int nfull = ragged ? nt - 1 : nt;
-    for (int t = 0; t < nfull; ++t) tile(std::false_type{}, t);
-    if (ragged) tile(std::true_type{}, nt - 1);
+    using B0 = std::integral_constant<int, 0>;
+    using B1 = std::integral_constant<int, 1>;
+    int t = 0;
+    for (; t + 1 < nfull; t += 2) {
+        tile(std::false_type{}, B0{}, t);
+        tile(std::false_type{}, B1{}, t + 1);
+    }
+    if (t < nfull) tile(std::false_type{}, B0{}, t);            // t is even here
+    if (ragged) {
+        if ((nt - 1) & 1) tile(std::true_type{}, B1{}, nt - 1);
+        else tile(std::true_type{}, B0{}, nt - 1);
+    }
     const float oscale = a.scale * (DROP ? a.keep_scale : 1.f);
     // dq tile: rows = q (registers), col = d (lane)
 #pragma unroll
@@ -669,8 +720,25 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a) 
         for (int i = 0; i < 16; ++i) { dk[dt][i] = 0.f; dv[dt][i] = 0.f; }
     const int kcol = wave * 32 + r;          // this lane's key column in the lots tile
 
-    for (int t = t_begin; t < nt; ++t) {
-        const int buf = t & 1;
+    // per-lane LDS addresses: Q / dO row fragments share one set, their transposed fragments another; the tile buffer
+    // is a compile-time constant of each instantiation of the step (the sweep is unrolled by two).
+    const bf16* raddr[D / 16];
+    const bf16* taddr[D / 32][2];
+#pragma unroll
+    for (int s = 0; s < D / 16; ++s) raddr[s] = lds + row_frag_lane_off<D>(16 * s, lane);
+#pragma unroll
+    for (int dt = 0; dt < D / 32; ++dt) {
+        int oa, ob;
+        tr_frag_lane_off<D, true>(32 * dt, lane, oa, ob);
+        taddr[dt][0] = lds + oa;
+        taddr[dt][1] = lds + ob;
+    }
+    const float* stat_lane = stat + 4 * h;                            // row constants of query rows 4h + {0..3} (+ 8g + 32qt)
+    const uint16_t* lots_lane = lots + 4 * h * kLotStride + kcol;
+
+    auto step = [&](auto buf_tag, int t) {
+        constexpr int buf = decltype(buf_tag)::value;
+        constexpr int QOFF = (buf * 2 + 0) * NS * TILE, DOFF = (buf * 2 + 1) * NS * TILE;
         if (t + 1 < nt) {
             ql.issue(qp, a.q_sn, (t + 1) * kKT, a.Nq, tid);
             dl.issue(dop, a.do_sn, (t + 1) * kKT, a.Nq, tid);
@@ -682,9 +750,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a) 
             f32x16 s, dp;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {      // accumulator registers 4g .. 4g+3 <-> query rows 32 qt + 8 g + 4 h + {0..3}
-                const int ro = 32 * qt + 8 * g + 4 * h;
-                const f32x4 l4 = *reinterpret_cast<const f32x4*>(stat + (buf * 2 + 0) * kKT + ro);
-                const f32x4 d4 = *reinterpret_cast<const f32x4*>(stat + (buf * 2 + 1) * kKT + ro);
+                const int ro = 32 * qt + 8 * g;
+                const f32x4 l4 = *reinterpret_cast<const f32x4*>(stat_lane + ((buf * 2 + 0) * kKT + ro));
+                const f32x4 d4 = *reinterpret_cast<const f32x4*>(stat_lane + ((buf * 2 + 1) * kKT + ro));
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { s[4 * g + j] = l4[j]; dp[4 * g + j] = d4[j]; }
             }
@@ -693,8 +761,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a) 
             for (int ks = 0; ks < D / 16; ++ks) {
 #pragma unroll
                 for (int sa = 0; sa < NS; ++sa) {
-                    bf16x8 qa = row_frag<D>(Qt(buf) + sa * TILE, 32 * qt, 16 * ks, lane);
-                    bf16x8 da = row_frag<D>(Dt(buf) + sa * TILE, 32 * qt, 16 * ks, lane);
+                    bf16x8 qa = *reinterpret_cast<const bf16x8*>(raddr[ks] + (QOFF + sa * TILE + 32 * qt * D));
+                    bf16x8 da = *reinterpret_cast<const bf16x8*>(raddr[ks] + (DOFF + sa * TILE + 32 * qt * D));
 #pragma unroll
                     for (int sb = 0; sb < NS; ++sb)
                         if (sa + sb <= 1) {
@@ -706,7 +774,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a) 
             float pd[16], ds[16];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int ro = 32 * qt + 8 * g + 4 * h;
+                const int ro = 32 * qt + 8 * g;
 #pragma unroll
                 for (int j = 0; j < 4; j += 2) {
                     const int i = 4 * g + j;
@@ -716,7 +784,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a) 
                     if constexpr (DROP) {   // 1/(1-p) is folded into delta (pre-divided) and the epilogue scales
 #pragma unroll
                         for (int e = 0; e < 2; ++e) {
-                            const bool keep = (int16_t)lots[((size_t)buf * kKT + ro + j + e) * kLotStride + kcol] >= (int16_t)ts;
+                            const bool keep = (int16_t)lots_lane[(buf * kKT + ro + j + e) * kLotStride] >= (int16_t)ts;
                             float pdv = keep ? p2[e] : 0.f;
                             asm("" : "+v"(pdv));     // select in fp32, so that the bf16 conversions below stay packed pairs
                             pd2[e] = pdv;
@@ -740,8 +808,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a) 
                 for (int dt = 0; dt < D / 32; ++dt) {
 #pragma unroll
                     for (int sb = 0; sb < NS; ++sb) {
-                        bf16x8 dof = tr_frag<D, true>(Dt(buf) + sb * TILE, 32 * qt + 16 * s2, 32 * dt, lane);
-                        bf16x8 qf = tr_frag<D, true>(Qt(buf) + sb * TILE, 32 * qt + 16 * s2, 32 * dt, lane);
+                        const int TO = sb * TILE + (32 * qt + 16 * s2) * D;
+                        bf16x8 dof = tr_frag_at(taddr[dt][0] + (DOFF + TO), taddr[dt][1] + (DOFF + TO));
+                        bf16x8 qf = tr_frag_at(taddr[dt][0] + (QOFF + TO), taddr[dt][1] + (QOFF + TO));
 #pragma unroll
                         for (int sa = 0; sa < NS; ++sa)
                             if (sa + sb <= 1) {
@@ -759,6 +828,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a) 
             gen_lots(t + 1, buf ^ 1);
         }
         __syncthreads();
+    };
+    {
+        using B0 = std::integral_constant<int, 0>;
+        using B1 = std::integral_constant<int, 1>;
+        int t = t_begin;
+        if (t < nt && (t & 1)) { step(B1{}, t); ++t; }            // align the sweep to an even tile
+        for (; t + 1 < nt; t += 2) {
+            step(B0{}, t);
+            step(B1{}, t + 1);
+        }
+        if (t < nt) step(B0{}, t);
     }
     // tiles: rows = key (registers), col = d (lane)
     const float ks = DROP ? a.keep_scale : 1.f;

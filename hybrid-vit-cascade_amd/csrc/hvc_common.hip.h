@@ -176,6 +176,31 @@ __device__ __forceinline__ bf16x8 tr_frag(const bf16* tile, int k0, int c0, int 
     return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 
+// Lane-resident LDS addresses: the XOR swizzle of tile_off<32|64> depends on row bits 1..3 only, so for rows
+// r0 + lane part with r0 a multiple of 16 the swizzled offset splits into a per-lane part (computed once, kept in
+// a register) and a compile-time part r0 * CW (folded into the instruction's immediate offset).  These return the
+// per-lane parts; the caller adds tile base and r0 * CW as constants.
+template <int CW>
+__device__ __forceinline__ int row_frag_lane_off(int k0, int lane) {       // row_frag<CW>(tile, r0, k0, lane) minus r0 * CW
+    static_assert(CW == 32 || CW == 64, "row bits above 3 must not enter the swizzle");
+    return tile_off<CW>(lane & 31, (k0 >> 3) + (lane >> 5));
+}
+template <int CW, bool PERM>
+__device__ __forceinline__ void tr_frag_lane_off(int c0, int lane, int& offa, int& offb) {   // tr_frag<CW,PERM>(tile, k0, c0, lane) minus k0 * CW
+    static_assert(CW == 32 || CW == 64, "row bits above 3 must not enter the swizzle");
+    const int g = lane >> 4, i = lane & 15, h = g >> 1;
+    const int col = c0 + 16 * (g & 1) + 4 * (i & 3);
+    const int rowa = (PERM ? 4 * h : 8 * h) + (i >> 2);
+    const int rowb = rowa + (PERM ? 8 : 4);
+    offa = tile_off<CW>(rowa, col >> 3) + (col & 7);
+    offb = tile_off<CW>(rowb, col >> 3) + (col & 7);
+}
+__device__ __forceinline__ bf16x8 tr_frag_at(const bf16* pa, const bf16* pb) {
+    bf16x4 lo = lds_tr4(pa);
+    bf16x4 hi = lds_tr4(pb);
+    return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
 // ---------------------------------------------------------------------------------
 // Counter-based dropout RNG shared by forward and backward kernels.
 // keep(idx) is a pure function of (seed, 64-bit element index); 16-bit threshold.
