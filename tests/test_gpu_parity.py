@@ -498,6 +498,73 @@ def test_direct_model_full_size_64_vs_oracle_and_psnr():
     assert abs(p32 - p_ref) < 0.1 and abs(p16 - p_ref) < 0.1, (p_ref, p32, p16)
 
 
+def test_attention_full_size_128_properties():
+    """BASELINE config #3 attention shape (A2-fix: 32^3 = 32768 tokens, h x d = 4 x 64), where no N x N oracle fits
+    in memory: size-independent properties of softmax attention and of its backward.
+      * rows of P sum to one: V = 1 gives O = 1, and then dQ = dK = 0 exactly in exact arithmetic;
+      * O is linear in V; <dO, O> = <dV, V> (adjoint of the V -> O map);
+      * probed query rows (first, last, tile seams) of O, LSE and dQ agree with a direct fp64 evaluation."""
+    from hvc import ops
+    B, H, N, D = 1, 4, 32768, 64
+    g = torch.Generator().manual_seed(128)
+    q, k, v = (torch.randn(B, N, H, D, generator=g).to(dev()) for _ in range(3))
+    do = torch.randn(B, N, H, D, generator=g).to(dev())
+    scale = D ** -0.5
+    o, lse = ops.attention_fwd(q, k, v, scale, 0.0, 0)
+    ones = torch.ones_like(v)
+    o1, lse1 = ops.attention_fwd(q, k, ones, scale, 0.0, 0)
+    assert (o1 - 1).abs().max().item() < 2e-5 and torch.equal(lse, lse1)
+    dq1, dk1, dv1 = ops.attention_bwd(q, k, ones, o1, do, lse1, scale, 0.0, 0)
+    assert dq1.abs().max().item() < 1e-4 * do.abs().max().item() and dk1.abs().max().item() < 1e-3 * do.abs().max().item()
+    v2 = torch.randn(B, N, H, D, generator=g).to(dev())
+    o2, _ = ops.attention_fwd(q, k, v2, scale, 0.0, 0)
+    o12, _ = ops.attention_fwd(q, k, 0.5 * v - 2.0 * v2, scale, 0.0, 0)
+    assert (o12 - (0.5 * o - 2.0 * o2)).abs().max().item() < 1e-4 * max(o.abs().max().item(), o2.abs().max().item())
+    dq, dk, dv = ops.attention_bwd(q, k, v, o, do, lse, scale, 0.0, 0)
+    lhs, rhs = (do.double() * o.double()).sum().item(), (dv.double() * v.double()).sum().item()
+    assert abs(lhs - rhs) < 1e-4 * (abs(lhs) + abs(rhs) + 1.0)
+    # probed rows against fp64: 8 query rows of one head for O / dQ, 8 key rows for dK / dV need all queries -> use O / dQ rows
+    b, hh = 0, 2
+    rows = torch.tensor([0, 1, 31, 32, 4095, 16384, 32766, 32767])
+    kd, vd = k[b, :, hh].double(), v[b, :, hh].double()
+    s_ = (q[b, rows, hh].double() @ kd.t()) * scale
+    p_ = torch.softmax(s_, dim=-1)
+    o_ref = p_ @ vd
+    assert (o[b, rows, hh].double() - o_ref).abs().max().item() < 1e-3 * o_ref.abs().max().item()
+    lse_ref = torch.logsumexp(s_, dim=-1)
+    assert (lse[b, hh, rows].double() - lse_ref).abs().max().item() < 1e-4
+    dp_ = do[b, rows, hh].double() @ vd.t()
+    ds_ = p_ * (dp_ - (p_ * dp_).sum(-1, keepdim=True))
+    dq_ref = ds_ @ kd * scale
+    assert (dq[b, rows, hh].double() - dq_ref).abs().max().item() < 1e-3 * dq_ref.abs().max().item()
+
+
+def test_direct_model_full_size_128_a2fix_geometry_and_bf16_psnr():
+    """BASELINE config #3 geometry (128^3; the reference raises here): the A2-fix sizes the token grid from the
+    stem's real output (32^3 = 32768 tokens); fp32 (split-bf16 MFMA) and bf16 runs of the same weights agree, and
+    their PSNR against the synthetic target differs by < 0.1 dB; the run is reproducible bit for bit."""
+    from direct_regression.model_direct import DirectCTRegression
+    from hvc import synthetic
+    from oracle import hvc_oracle as O
+    torch.manual_seed(0)
+    m = DirectCTRegression(volume_size=(128, 128, 128)).eval()
+    assert tuple(m.vit_backbone.downsampled_size) == (32, 32, 32) and m.vit_backbone.pos_embed.shape == (1, 32768, 256)
+    gen = torch.Generator().manual_seed(22)
+    with torch.no_grad():
+        for blk in m.vit_backbone.blocks:
+            blk.adaln.linear.weight.copy_(torch.randn(blk.adaln.linear.weight.shape, generator=gen) * 0.02)
+    xr, ct = synthetic.sample(1, (128, 128, 128), 512)
+    m.to(dev())
+    with torch.no_grad():
+        y32 = m(xr[None].to(dev()))
+        y32b = m(xr[None].to(dev()))
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y16 = m(xr[None].to(dev())).float()
+    assert y32.shape == (1, 1, 128, 128, 128) and torch.isfinite(y32).all() and torch.equal(y32, y32b)
+    assert ((y16 - y32).norm() / y32.norm()).item() < 2e-2
+    assert abs(O.psnr(y32.cpu(), ct[None]) - O.psnr(y16.cpu(), ct[None])) < 0.1
+
+
 @pytest.mark.parametrize("mode", ["f32", "bf16"])
 def test_cascade_refiners_vs_golden(golden, mode):
     """Shared multi-scale X-ray encoder + stage-2 / stage-3 refiners (reduced sizes) chained as
