@@ -313,8 +313,16 @@ int hvc_trilinear_fwd(const float* src, float* dst, int B, int d, int h, int w, 
     if (!src || !dst || B < 1 || d < 1 || h < 1 || w < 1 || D < 1 || H < 1 || W < 1) return fail(HVC_E_BADARG, "trilinear: bad operand");
     return hip_result(hvc::trilinear_launch(src, dst, B, d, h, w, D, H, W, align_corners != 0, false, (hipStream_t)stream), "trilinear_fwd");
 }
-int hvc_trilinear_bwd(const float* dout, float* dsrc, int B, int d, int h, int w, int D, int H, int W, int align_corners, void* stream) {
+int64_t hvc_trilinear_bwd_workspace(int B, int d, int h, int w, int D, int H, int W) {
+    if (B < 1 || d < 1 || h < 1 || w < 1 || D < 1 || H < 1 || W < 1) return 0;
+    return hvc::trilinear_bwd_workspace_floats(B, d, h, w, D, H, W);
+}
+int hvc_trilinear_bwd(const float* dout, float* dsrc, float* workspace, int B, int d, int h, int w, int D, int H, int W, int align_corners,
+                      void* stream) {
     if (!dout || !dsrc || B < 1 || d < 1 || h < 1 || w < 1 || D < 1 || H < 1 || W < 1) return fail(HVC_E_BADARG, "trilinear: bad operand");
+    if (workspace)
+        return hip_result(hvc::trilinear_bwd_separable_launch(dout, dsrc, workspace, B, d, h, w, D, H, W, align_corners != 0, (hipStream_t)stream),
+                          "trilinear_bwd");
     return hip_result(hvc::trilinear_launch(dout, dsrc, B, d, h, w, D, H, W, align_corners != 0, true, (hipStream_t)stream), "trilinear_bwd");
 }
 

@@ -141,6 +141,9 @@ hipError_t im2col_launch(const ConvGeom& g, const void* src, void* col, int is_b
 hipError_t col2im_launch(const ConvGeom& g, const void* dcol, void* dsrc, int is_bf16, hipStream_t st);
 hipError_t trilinear_launch(const float* src, float* dst, int B, int d, int h, int w, int D, int H, int W, bool align_corners, bool bwd,
                             hipStream_t st);
+int64_t trilinear_bwd_workspace_floats(int B, int d, int h, int w, int D, int H, int W);
+hipError_t trilinear_bwd_separable_launch(const float* dout, float* dsrc, float* workspace, int B, int d, int h, int w, int D, int H, int W,
+                                          bool align_corners, hipStream_t st);
 
 struct PoolGeom { int N, H, W, C, HP, WP, k, s, p; };
 struct NormArgs {

@@ -210,6 +210,28 @@ __global__ __launch_bounds__(256) void trilinear_bwd_kernel(const float* __restr
     }
 }
 
+// Adjoint of the 1-D interpolation along one axis of [outer][fine][inner] -> [outer][coarse][inner]; thread per output
+// element, inner fastest (coalesced); the ~2/r + 2 fine candidates of a coarse index are walked in a fixed order.
+__global__ __launch_bounds__(256) void axis_adjoint_kernel(const float* __restrict__ src, float* __restrict__ dst, int64_t outer, int fine,
+                                                            int coarse, int64_t inner, int ac) {
+    const AxisMap m = axis_map(coarse, fine, ac);
+    const int64_t total = outer * coarse * inner;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int64_t n = idx % inner;
+        const int i = (int)((idx / inner) % coarse);
+        const int64_t o = idx / (inner * coarse);
+        int lo, hi;
+        axis_range(i, m, fine, lo, hi);
+        const float* s = src + (o * fine) * inner + n;
+        float acc = 0.f;
+        for (int f = lo; f <= hi; ++f) {
+            const float wgt = axis_w(f, i, m, coarse);
+            if (wgt != 0.f) acc += wgt * s[(int64_t)f * inner];
+        }
+        dst[idx] = acc;
+    }
+}
+
 int grid_for(int64_t work) {
     int64_t blocks = (work + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;
@@ -253,6 +275,21 @@ hipError_t trilinear_launch(const float* src, float* dst, int B, int d, int h, i
     const int ac = align_corners ? 1 : 0;
     if (!bwd) hipLaunchKernelGGL(trilinear_fwd_kernel, dim3(grid_for((int64_t)B * D * H * W)), dim3(256), 0, st, src, dst, B, d, h, w, D, H, W, ac);
     else hipLaunchKernelGGL(trilinear_bwd_kernel, dim3(grid_for((int64_t)B * d * h * w * 64)), dim3(256), 0, st, src, dst, B, d, h, w, D, H, W, ac);
+    return hipGetLastError();
+}
+
+int64_t trilinear_bwd_workspace_floats(int B, int d, int h, int w, int D, int H, int W) {
+    return (int64_t)B * D * H * w + (int64_t)B * D * h * w;      // after the W pass | after the H pass
+}
+
+hipError_t trilinear_bwd_separable_launch(const float* dout, float* dsrc, float* workspace, int B, int d, int h, int w, int D, int H, int W,
+                                          bool align_corners, hipStream_t st) {
+    const int ac = align_corners ? 1 : 0;
+    float* t1 = workspace;                                  // [B*D*H][w]
+    float* t2 = workspace + (int64_t)B * D * H * w;         // [B*D][h][w]
+    hipLaunchKernelGGL(axis_adjoint_kernel, dim3(grid_for((int64_t)B * D * H * w)), dim3(256), 0, st, dout, t1, (int64_t)B * D * H, W, w, (int64_t)1, ac);
+    hipLaunchKernelGGL(axis_adjoint_kernel, dim3(grid_for((int64_t)B * D * h * w)), dim3(256), 0, st, t1, t2, (int64_t)B * D, H, h, (int64_t)w, ac);
+    hipLaunchKernelGGL(axis_adjoint_kernel, dim3(grid_for((int64_t)B * d * h * w)), dim3(256), 0, st, t2, dsrc, (int64_t)B, D, d, (int64_t)h * w, ac);
     return hipGetLastError();
 }
 

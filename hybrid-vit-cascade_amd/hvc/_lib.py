@@ -38,7 +38,8 @@ SIGNATURES = {
     "hvc_im2col": (_i, [_p, _p] + [_i] * 13 + [_i64, _i, _p]),
     "hvc_col2im": (_i, [_p, _p] + [_i] * 13 + [_i64, _i, _p]),
     "hvc_trilinear_fwd": (_i, [_p, _p] + [_i] * 8 + [_p]),
-    "hvc_trilinear_bwd": (_i, [_p, _p] + [_i] * 8 + [_p]),
+    "hvc_trilinear_bwd_workspace": (_i64, [_i] * 7),
+    "hvc_trilinear_bwd": (_i, [_p, _p, _p] + [_i] * 8 + [_p]),
     "hvc_norm_workspace": (_i64, [_i, _i, _i, _i]),
     "hvc_groupnorm_act_fwd": (_i, [_p] * 6 + [_i, _i, _i, _i, _f, _i, _i, _p]),
     "hvc_groupnorm_act_bwd": (_i, [_p] * 9 + [_i, _i, _i, _i, _i, _i, _p]),

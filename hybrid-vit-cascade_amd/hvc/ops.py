@@ -376,12 +376,18 @@ def trilinear_fwd(x, size, align_corners=True):
     return y
 
 
-def trilinear_bwd(dy, in_size, align_corners=True):
+def trilinear_bwd(dy, in_size, align_corners=True, separable=True):
+    """Adjoint of trilinear_fwd.  separable=True: three 1-D passes through a workspace; False: single-pass 3-D gather."""
     _dev(dy)
     _f32c(dy, "dy")
     B, D, H, W = dy.shape
     dx = torch.empty((B, *in_size), dtype=torch.float32, device=dy.device)
-    check(_lib.load().hvc_trilinear_bwd(dy.data_ptr(), dx.data_ptr(), B, *in_size, D, H, W, int(align_corners), _stream()), "hvc_trilinear_bwd")
+    lib = _lib.load()
+    ws = None
+    if separable:
+        ws = torch.empty((lib.hvc_trilinear_bwd_workspace(B, *in_size, D, H, W),), dtype=torch.float32, device=dy.device)
+    check(lib.hvc_trilinear_bwd(dy.data_ptr(), dx.data_ptr(), _ptr(ws), B, *in_size, D, H, W, int(align_corners), _stream()),
+          "hvc_trilinear_bwd")
     return dx
 
 

@@ -707,9 +707,10 @@ def test_trilinear_resize_kernels_vs_aten_semantics(shape, align_corners):
     ref = F.interpolate(xr[:, None], size=out, mode="trilinear", align_corners=align_corners)[:, 0]
     ref.backward(dy)
     y = ops.trilinear_fwd(x.to(dev()), out, align_corners)
-    dx = ops.trilinear_bwd(dy.to(dev()), (d, h, w), align_corners)
     assert (y.cpu() - ref.detach()).abs().max().item() < 1e-5
-    assert (dx.cpu() - xr.grad).abs().max().item() < 1e-4 * max(1.0, xr.grad.abs().max().item())
+    for separable in (True, False):         # three 1-D adjoint passes / single-pass 3-D gather
+        dx = ops.trilinear_bwd(dy.to(dev()), (d, h, w), align_corners, separable=separable)
+        assert (dx.cpu() - xr.grad).abs().max().item() < 1e-4 * max(1.0, xr.grad.abs().max().item()), separable
 
 
 @pytest.mark.timeout(600)
