@@ -65,23 +65,41 @@ struct OperandTile {
     static constexpr int CPT = ROWS * CPR / 256;
     static constexpr int IMG = ROWS * CW;
     Chunk8<T> reg[CPT];
+    const T* next;          // this thread's first chunk in the next k-tile (interior fast path)
+    int64_t rstep, kstep;   // elements between a thread's consecutive chunks / between consecutive k-tiles
 
-    // base: operand pointer; ld; i0: first row(i) of this tile; ni: extent of i; k0: first k; nk: extent of k
+    // i0: first row(i) of this output tile, k0: first k of the first k-tile that will be requested; tiles are then
+    // requested in k order.
+    __device__ __forceinline__ void init(const T* base, int64_t ld, int i0, int k0, int tid) {
+        const int row = tid / CPR, ch = tid % CPR;
+        rstep = (int64_t)(256 / CPR) * ld;
+        if constexpr (!KM) { next = base + (int64_t)(i0 + row) * ld + k0 + ch * 8; kstep = BK; }
+        else { next = base + (int64_t)(k0 + row) * ld + i0 + ch * 8; kstep = (int64_t)BK * ld; }
+    }
+    // base: operand pointer; ld; i0: first row(i) of this tile; ni: extent of i; k0: first k; nk: extent of k.
+    // A tile that lies fully inside the operand (and is 16-byte addressable) takes unconditional vector loads from
+    // incrementally advanced addresses; edge tiles go through the per-chunk bounds path.
     __device__ __forceinline__ void issue(const T* base, int64_t ld, int i0, int ni, int k0, int nk, bool vec, int tid) {
+        if (vec && i0 + 128 <= ni && k0 + BK <= nk) {
 #pragma unroll
-        for (int c = 0; c < CPT; ++c) {
-            int id = tid + 256 * c;
-            int row = id / CPR, ch = id % CPR;
-            if constexpr (!KM) {
-                int i = i0 + row, k = k0 + ch * 8;
-                int nv = (i < ni) ? (nk - k) : 0;
-                reg[c] = load_chunk<T>(base + (int64_t)i * ld + k, nv > 8 ? 8 : nv, vec);
-            } else {
-                int k = k0 + row, i = i0 + ch * 8;
-                int nv = (k < nk) ? (ni - i) : 0;
-                reg[c] = load_chunk<T>(base + (int64_t)k * ld + i, nv > 8 ? 8 : nv, vec);
+            for (int c = 0; c < CPT; ++c) reg[c] = load_chunk<T>(next + c * rstep, 8, true);
+        } else {
+#pragma unroll
+            for (int c = 0; c < CPT; ++c) {
+                int id = tid + 256 * c;
+                int row = id / CPR, ch = id % CPR;
+                if constexpr (!KM) {
+                    int i = i0 + row, k = k0 + ch * 8;
+                    int nv = (i < ni) ? (nk - k) : 0;
+                    reg[c] = load_chunk<T>(base + (int64_t)i * ld + k, nv > 8 ? 8 : nv, vec);
+                } else {
+                    int k = k0 + row, i = i0 + ch * 8;
+                    int nv = (k < nk) ? (ni - i) : 0;
+                    reg[c] = load_chunk<T>(base + (int64_t)k * ld + i, nv > 8 ? 8 : nv, vec);
+                }
             }
         }
+        next += kstep;
     }
     __device__ __forceinline__ void commit(bf16* images, int tid) {
 #pragma unroll
@@ -147,6 +165,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
     const int per_split = (nkt_all + g.splitk - 1) / g.splitk;
     const int kt_begin = split * per_split;
     const int kt_end = min(nkt_all, kt_begin + per_split);
+    ta.init(Ap, g.lda, i0, kt_begin * BK, tid);
+    tb.init(Bp, g.ldb, j0, kt_begin * BK, tid);
     ta.issue(Ap, g.lda, i0, g.M, kt_begin * BK, g.K, g.vec_a != 0, tid);
     tb.issue(Bp, g.ldb, j0, g.N, kt_begin * BK, g.K, g.vec_b != 0, tid);
     ta.commit(At(0), tid);
