@@ -17,6 +17,7 @@
 // buffered with register-staged global loads issued one k-tile ahead.
 #include "hvc_common.hip.h"
 #include "hvc_kernels.h"
+#include <type_traits>
 
 namespace hvc {
 namespace {
@@ -64,7 +65,7 @@ struct OperandTile {
     static constexpr int CPR = CW / 8;
     static constexpr int CPT = ROWS * CPR / 256;
     static constexpr int IMG = ROWS * CW;
-    Chunk8<T> reg[CPT];
+    Chunk8<T> reg[2][CPT];  // two staging sets: tiles are fetched two k-steps ahead of their use
     const T* next;          // this thread's first chunk in the next k-tile (interior fast path)
     int64_t rstep, kstep;   // elements between a thread's consecutive chunks / between consecutive k-tiles
 
@@ -79,10 +80,11 @@ struct OperandTile {
     // base: operand pointer; ld; i0: first row(i) of this tile; ni: extent of i; k0: first k; nk: extent of k.
     // A tile that lies fully inside the operand (and is 16-byte addressable) takes unconditional vector loads from
     // incrementally advanced addresses; edge tiles go through the per-chunk bounds path.
+    template <int SET>
     __device__ __forceinline__ void issue(const T* base, int64_t ld, int i0, int ni, int k0, int nk, bool vec, int tid) {
         if (vec && i0 + 128 <= ni && k0 + BK <= nk) {
 #pragma unroll
-            for (int c = 0; c < CPT; ++c) reg[c] = load_chunk<T>(next + c * rstep, 8, true);
+            for (int c = 0; c < CPT; ++c) reg[SET][c] = load_chunk<T>(next + c * rstep, 8, true);
         } else {
 #pragma unroll
             for (int c = 0; c < CPT; ++c) {
@@ -91,23 +93,24 @@ struct OperandTile {
                 if constexpr (!KM) {
                     int i = i0 + row, k = k0 + ch * 8;
                     int nv = (i < ni) ? (nk - k) : 0;
-                    reg[c] = load_chunk<T>(base + (int64_t)i * ld + k, nv > 8 ? 8 : nv, vec);
+                    reg[SET][c] = load_chunk<T>(base + (int64_t)i * ld + k, nv > 8 ? 8 : nv, vec);
                 } else {
                     int k = k0 + row, i = i0 + ch * 8;
                     int nv = (k < nk) ? (ni - i) : 0;
-                    reg[c] = load_chunk<T>(base + (int64_t)k * ld + i, nv > 8 ? 8 : nv, vec);
+                    reg[SET][c] = load_chunk<T>(base + (int64_t)k * ld + i, nv > 8 ? 8 : nv, vec);
                 }
             }
         }
         next += kstep;
     }
+    template <int SET>
     __device__ __forceinline__ void commit(bf16* images, int tid) {
 #pragma unroll
         for (int c = 0; c < CPT; ++c) {
             int id = tid + 256 * c;
             int row = id / CPR, ch = id % CPR;
             bf16x8 im[NS];
-            chunk_split<T>(reg[c], im);
+            chunk_split<T>(reg[SET][c], im);
 #pragma unroll
             for (int s = 0; s < NS; ++s) tile_store<CW>(images + s * IMG, row, ch, im[s]);
         }
@@ -165,12 +168,19 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
     const int per_split = (nkt_all + g.splitk - 1) / g.splitk;
     const int kt_begin = split * per_split;
     const int kt_end = min(nkt_all, kt_begin + per_split);
+    // Software pipeline, two k-tiles deep: while tile kt is multiplied out of LDS buffer kt & 1, tile kt+1 sits in one
+    // register set (written to the other LDS buffer at the end of the step) and tile kt+2 is in flight into the other
+    // set - a load has two compute phases to arrive, which matters at the blocks' K = 256 (4 tiles).
     ta.init(Ap, g.lda, i0, kt_begin * BK, tid);
     tb.init(Bp, g.ldb, j0, kt_begin * BK, tid);
-    ta.issue(Ap, g.lda, i0, g.M, kt_begin * BK, g.K, g.vec_a != 0, tid);
-    tb.issue(Bp, g.ldb, j0, g.N, kt_begin * BK, g.K, g.vec_b != 0, tid);
-    ta.commit(At(0), tid);
-    tb.commit(Bt(0), tid);
+    ta.template issue<0>(Ap, g.lda, i0, g.M, kt_begin * BK, g.K, g.vec_a != 0, tid);
+    tb.template issue<0>(Bp, g.ldb, j0, g.N, kt_begin * BK, g.K, g.vec_b != 0, tid);
+    if (kt_begin + 1 < kt_end) {
+        ta.template issue<1>(Ap, g.lda, i0, g.M, (kt_begin + 1) * BK, g.K, g.vec_a != 0, tid);
+        tb.template issue<1>(Bp, g.ldb, j0, g.N, (kt_begin + 1) * BK, g.K, g.vec_b != 0, tid);
+    }
+    ta.template commit<0>(At(0), tid);
+    tb.template commit<0>(Bt(0), tid);
     __syncthreads();
 
     f32x16 acc[2][2];
@@ -181,11 +191,12 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[mi][ni][i] = 0.f;
 
-    for (int kt = kt_begin; kt < kt_end; ++kt) {
-        const int buf = (kt - kt_begin) & 1;
-        if (kt + 1 < kt_end) {
-            ta.issue(Ap, g.lda, i0, g.M, (kt + 1) * BK, g.K, g.vec_a != 0, tid);
-            tb.issue(Bp, g.ldb, j0, g.N, (kt + 1) * BK, g.K, g.vec_b != 0, tid);
+    // one k-step: BUF = LDS buffer holding tile kt; register set BUF ^ 1 holds tile kt+1; tile kt+2 goes to set BUF.
+    auto kstep = [&](auto buf_tag, int kt) {
+        constexpr int buf = decltype(buf_tag)::value;
+        if (kt + 2 < kt_end) {
+            ta.template issue<buf>(Ap, g.lda, i0, g.M, (kt + 2) * BK, g.K, g.vec_a != 0, tid);
+            tb.template issue<buf>(Bp, g.ldb, j0, g.N, (kt + 2) * BK, g.K, g.vec_b != 0, tid);
         }
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
@@ -208,10 +219,20 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
                             if (sa + sb <= 1) acc[mi][ni] = mfma32(af[sa][mi], bfr[sb][ni], acc[mi][ni]);
         }
         if (kt + 1 < kt_end) {
-            ta.commit(At(buf ^ 1), tid);
-            tb.commit(Bt(buf ^ 1), tid);
+            ta.template commit<buf ^ 1>(At(buf ^ 1), tid);
+            tb.template commit<buf ^ 1>(Bt(buf ^ 1), tid);
         }
         __syncthreads();
+    };
+    {
+        using B0 = std::integral_constant<int, 0>;
+        using B1 = std::integral_constant<int, 1>;
+        int kt = kt_begin;
+        for (; kt + 1 < kt_end; kt += 2) {
+            kstep(B0{}, kt);
+            kstep(B1{}, kt + 1);
+        }
+        if (kt < kt_end) kstep(B0{}, kt);
     }
 
     // ---- epilogue: stage the 128 x 128 fp32 tile through LDS (the operand buffers are free now) so that
