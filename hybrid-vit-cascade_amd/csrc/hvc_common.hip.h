@@ -202,18 +202,13 @@ __device__ __forceinline__ bf16x8 tr_frag_at(const bf16* pa, const bf16* pb) {
 }
 
 // ---------------------------------------------------------------------------------
-// Counter-based dropout RNG shared by forward and backward kernels.
-// keep(idx) is a pure function of (seed, 64-bit element index); 16-bit threshold.
+// Counter-based dropout RNG shared by forward and backward kernels: keep(...) is a pure function of
+// (seed, element coordinates); 16-bit thresholds.
 // ---------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t mix32(uint32_t x) {
     x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
     return x;
 }
-// Returns 32 random bits for the pair-index idx (two 16-bit lots).
-__device__ __forceinline__ uint32_t rng_pair(uint32_t seed_lo, uint32_t seed_hi, uint32_t idx_lo, uint32_t idx_hi) {
-    return mix32(mix32(idx_lo ^ seed_lo) + (idx_hi ^ seed_hi) * 0x9E3779B9U);
-}
-
 // Dropout of a row-major (rows x cols) activation (GEMM-epilogue dropouts and their backward): one well-mixed
 // 32-bit key per row, then one multiply-xorshift round per 4 consecutive columns yielding four 16-bit lots
 // (element kept when lot >= thresh).  ~3 instructions / element when a thread owns 8 consecutive columns,
@@ -276,11 +271,6 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
 }
 
