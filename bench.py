@@ -247,7 +247,7 @@ def main():
                                             "launches_per_step": v[2] / share_steps, "avg_launch_ms": 1e3 * v[0] / v[2]}
                                         for k, v in sorted(agg2.items())}
             out["kernel_time_share_note"] = "from an extra untimed pass with every attention / GEMM launch bracketed" if full else "timed region"
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # host-CPU baseline: rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if world > 1:
