@@ -23,8 +23,9 @@ for p in (0.0, 0.1):
     ops.PROFILE = None
     print(f"p={p}: " + "  ".join(f"{n.replace('attn_', '').replace('_kernel', '')} {min(x):.3f}" for n, x in sorted(acc.items()) if "delta" not in n), flush=True)
 ''' % ROOT
-libs = sys.argv[1:3]
-for rnd in range(int(sys.argv[3]) if len(sys.argv) > 3 else 2):
+rounds = int(sys.argv[-1]) if sys.argv[-1].isdigit() else 2
+libs = [a for a in sys.argv[1:] if not a.isdigit()]
+for rnd in range(rounds):
     for lib in libs:
         out = subprocess.run([sys.executable, "-c", CHILD, lib], capture_output=True, text=True)
         print(os.path.basename(lib), "|", " | ".join(l for l in out.stdout.strip().splitlines()), flush=True)
