@@ -116,11 +116,15 @@ struct TileLoader {
 __device__ __forceinline__ uint32_t drop_rowkey(const AttnArgs& a, int bh, int q) {
     return mix32(((uint32_t)(bh * a.Nq + q) * 0x9E3779B1u) ^ a.seed_lo) ^ a.seed_hi;
 }
-constexpr uint32_t kKeyMul = 0x85EBCA6Bu, kLotMulA = 0x7feb352dU, kLotMulB = 0x846ca68bU;
-__device__ __forceinline__ uint32_t drop_mix(uint32_t rowkey, uint32_t keyterm) {   // keyterm = (key >> 2) * kKeyMul
-    uint32_t x = rowkey + keyterm;
-    return x ^ (x >> 16);
-}
+// The word that is multiplied: x = ((rowkey ^ (j & 1 ? H : 0)) + tile * T) ^ A[j >> 3] ^ B[(j >> 1) & 3], tile = key >> 6,
+// j = (key >> 2) & 15 the 4-key group inside the 64-key tile, all constants fixed odd words.  Every kernel gets x
+// for one instruction per group whatever its register layout: in the query-on-lane kernels j & 1 is the lane half,
+// folded into the row key once, and A ^ B is a compile-time constant per group; the dK/dV lot generator keeps
+// both parities of its row key per tile with its thread's A term folded in.
+constexpr uint32_t kLotMulA = 0x7feb352dU, kLotMulB = 0x846ca68bU;
+constexpr uint32_t kTileAdd = 0x9E3779B9u, kGrpH = 0xB55A4F09u;
+__host__ __device__ constexpr uint32_t drop_grp_a(int j8) { return j8 ? 0xC2B2AE35u : 0x85EBCA6Bu; }
+__host__ __device__ constexpr uint32_t drop_grp_b(int m) { return m == 0 ? 0x27D4EB2Fu : m == 1 ? 0x165667B1u : m == 2 ? 0xD3A2646Cu : 0xFD7046C5u; }
 __device__ __forceinline__ uint32_t drop_lots(uint32_t mixed, uint32_t mul) {        // two 16-bit lots
     uint32_t y = mixed * mul;
     return y ^ (y >> 15);
@@ -128,10 +132,9 @@ __device__ __forceinline__ uint32_t drop_lots(uint32_t mixed, uint32_t mul) {   
 __device__ __forceinline__ int drop_ts(const AttnArgs& a) { return (int)a.drop_thresh - 32768; }
 __device__ __forceinline__ bool drop_keep_lo(uint32_t w, int ts) { return (int16_t)w >= (int16_t)ts; }
 __device__ __forceinline__ bool drop_keep_hi(uint32_t w, int ts) { return (int32_t)w >= ts * 65536; }
-// keep flags of the four consecutive keys 4*(key>>2) .. +3
-__device__ __forceinline__ void drop_keep4(uint32_t rowkey, int key, int ts, bool (&keep)[4]) {
-    const uint32_t m = drop_mix(rowkey, (uint32_t)(key >> 2) * kKeyMul);
-    const uint32_t a = drop_lots(m, kLotMulA), b = drop_lots(m, kLotMulB);
+// keep flags of the four consecutive keys of one group from its mixed word
+__device__ __forceinline__ void drop_keep4(uint32_t mixed, int ts, bool (&keep)[4]) {
+    const uint32_t a = drop_lots(mixed, kLotMulA), b = drop_lots(mixed, kLotMulB);
     keep[0] = drop_keep_lo(a, ts); keep[1] = drop_keep_hi(a, ts);
     keep[2] = drop_keep_lo(b, ts); keep[3] = drop_keep_hi(b, ts);
 }
@@ -246,7 +249,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 3 : 2) void attn_fwd_kernel(c
 #pragma unroll
         for (int i = 0; i < 16; ++i) o[dt][i] = 0.f;
 
-    const uint32_t rowkey = DROP ? drop_rowkey(a, bh, qrow_c) : 0u;
+    const uint32_t rowkey = DROP ? drop_rowkey(a, bh, qrow_c) ^ (h ? kGrpH : 0u) : 0u;      // lane half = low bit of the group index
     const uint32_t tm1x2 = DROP ? ((uint32_t)(drop_ts(a) - 1) & 0xffffu) * 0x10001u : 0u;
 
     // Per-lane LDS addresses of the K row fragments (one per 16-wide d step) and the transposed V fragments (two row
@@ -290,6 +293,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 3 : 2) void attn_fwd_kernel(c
             }
         }
         const int kbase = t * kKT;
+        const uint32_t rk_tile = rowkey + (uint32_t)t * kTileAdd;
         if constexpr (MASK) {
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
@@ -344,9 +348,8 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 3 : 2) void attn_fwd_kernel(c
                 acc_split<NS>(x, pf);
                 if constexpr (DROP) {      // packed keep masks onto the bf16 pairs: registers 8 s2 .. + 7 = two 4-key groups
 #pragma unroll
-                    for (int g2 = 0; g2 < 2; ++g2) {
-                        const int key = kbase + 32 * kt + acc_row(8 * s2 + 4 * g2, h);
-                        const uint32_t m = drop_mix(rowkey, (uint32_t)(key >> 2) * kKeyMul);
+                    for (int g2 = 0; g2 < 2; ++g2) {      // group j = 8 kt + 2 (2 s2 + g2) + h of tile t
+                        const uint32_t m = rk_tile ^ (drop_grp_a(kt) ^ drop_grp_b(2 * s2 + g2));
                         const uint32_t ma = drop_keepmask2(drop_lots(m, kLotMulA), tm1x2);
                         const uint32_t mb = drop_keepmask2(drop_lots(m, kLotMulB), tm1x2);
 #pragma unroll
@@ -502,7 +505,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
     for (int dt = 0; dt < D / 32; ++dt)
 #pragma unroll
         for (int i = 0; i < 16; ++i) dq[dt][i] = 0.f;
-    const uint32_t rowkey = DROP ? drop_rowkey(a, bh, qrow_c) : 0u;
+    const uint32_t rowkey = DROP ? drop_rowkey(a, bh, qrow_c) ^ (h ? kGrpH : 0u) : 0u;      // lane half = low bit of the group index
     const int ts = drop_ts(a);
 
     // per-lane LDS addresses (see the forward kernel): K / V row fragments share one set, K^T fragments another
@@ -554,7 +557,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
             for (int i = 0; i < 16; i += 4) {
                 const int key = kbase + 32 * kt + acc_row(i, h);
                 bool keep[4] = {true, true, true, true};
-                if constexpr (DROP) drop_keep4(rowkey, key, ts, keep);
+                if constexpr (DROP) drop_keep4((rowkey + (uint32_t)t * kTileAdd) ^ (drop_grp_a(kt) ^ drop_grp_b(i >> 2)), ts, keep);
 #pragma unroll
                 for (int j = 0; j < 4; j += 2) {
                     f32x2 p2 = {__builtin_amdgcn_exp2f(st[kt][i + j]), __builtin_amdgcn_exp2f(st[kt][i + j + 1])};
@@ -690,12 +693,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a) 
         if constexpr (DROP) {
             const int ql = tid >> 2, part = tid & 3;
             const int q = min(t * kKT + ql, a.Nq - 1);
-            const uint32_t rk = drop_rowkey(a, bh, q);
-            const int key0 = kb * kQB + 32 * part;
+            // keys 128 kb + 32 part + 4 u .. + 3: 64-key tile 2 kb + (part >> 1), group j = 8 (part & 1) + u
+            const uint32_t rk0 = drop_rowkey(a, bh, q), tadd = (uint32_t)(2 * kb + (part >> 1)) * kTileAdd;
+            const uint32_t rk[2] = {(rk0 + tadd) ^ drop_grp_a(part & 1), ((rk0 ^ kGrpH) + tadd) ^ drop_grp_a(part & 1)};
             uint32_t* dst = reinterpret_cast<uint32_t*>(lots + ((size_t)buf * kKT + ql) * kLotStride + 32 * part);
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const uint32_t m = drop_mix(rk, (uint32_t)((key0 + 4 * u) >> 2) * kKeyMul);
+                const uint32_t m = rk[u & 1] ^ drop_grp_b(u >> 1);
                 dst[2 * u] = drop_lots(m, kLotMulA);
                 dst[2 * u + 1] = drop_lots(m, kLotMulB);
             }
