@@ -31,6 +31,7 @@ sys.path.insert(0, ROOT)
 WORKLOADS = {
     "direct128": dict(volume=(128, 128, 128), batch=2, name="Direct baseline 128^3, bf16, batch=2/GPU (BASELINE configs[2] per-GPU slice)"),
     "direct64": dict(volume=(64, 64, 64), batch=4, name="Direct baseline 64^3, bf16, batch=4 (BASELINE configs[1])"),
+    "direct256": dict(volume=(256, 256, 256), batch=1, name="Direct model at 256^3 (north_star's third resolution), bf16, batch=1/GPU"),
 }
 MFMA_BF16_PEAK_TFLOPS = 2500.0     # dense, /opt/skills/guides/MI355X_MICROARCH.md
 
@@ -202,7 +203,7 @@ def main():
         vols = wl["batch"] * world * args.steps
         value = vols / elapsed
         out = {
-            "metric": "CT volumes/sec fwd+bwd @128^3 direct model" if args.workload == "direct128" else "CT volumes/sec fwd+bwd @64^3 direct model",
+            "metric": f"CT volumes/sec fwd+bwd @{wl['volume'][0]}^3 direct model",
             "value": value, "unit": "volumes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
