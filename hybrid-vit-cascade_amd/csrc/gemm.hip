@@ -423,9 +423,50 @@ int64_t gemm_workspace_floats(int M, int N, int K) {
     return want >= 2 ? (int64_t)want * M * N : 0;
 }
 
+namespace {
+// C[m][j] = alpha * sum_k A[m][k] B[j][k] + bias[j] for M <= 8 rows, fp32, both operands k-contiguous: the conditioning
+// vectors' Linears (AdaLN 1024 -> 1536, time / context MLPs; M = batch).  A 128 x 128 MFMA tile would be 98 % padding
+// and 12 workgroups; this streams the weight matrix once with one wavefront per output column (exact fp32 FMAs).
+template <int MR>
+__global__ __launch_bounds__(256) void gemv_rows_kernel(const GemmArgs g) {
+    const int lane = threadIdx.x & 63;
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= g.N) return;
+    const float* A = reinterpret_cast<const float*>(g.A);
+    const float* brow = reinterpret_cast<const float*>(g.B) + (int64_t)j * g.ldb;
+    float acc[MR];
+#pragma unroll
+    for (int m = 0; m < MR; ++m) acc[m] = 0.f;
+    for (int k = 4 * lane; k < g.K; k += 256) {
+        const f32x4 w = *reinterpret_cast<const f32x4*>(brow + k);
+#pragma unroll
+        for (int m = 0; m < MR; ++m) {
+            if (m < g.M) {
+                const f32x4 x = *reinterpret_cast<const f32x4*>(A + (int64_t)m * g.lda + k);
+                acc[m] += (x[0] * w[0] + x[1] * w[1]) + (x[2] * w[2] + x[3] * w[3]);
+            }
+        }
+    }
+    float* C = reinterpret_cast<float*>(g.C);
+#pragma unroll
+    for (int m = 0; m < MR; ++m) {
+        const float s = wave_sum(acc[m]);
+        if (lane == 0 && m < g.M) C[(int64_t)m * g.ldc + j] = s * g.alpha + (g.bias ? g.bias[j] : 0.f);
+    }
+}
+}  // namespace
+
 hipError_t gemm_launch(const GemmArgs& g, hipStream_t st) {
     if (g.in_bf16) return g.out_bf16 ? launch_layout<bf16, bf16>(g, st) : launch_layout<bf16, float>(g, st);
     if (g.out_bf16) return hipErrorInvalidValue;
+    const bool plain_rows = g.M <= 8 && !g.a_kmajor && !g.b_kmajor && g.act == kActNone && !g.aux && !g.zsave && !g.gate && !g.residual &&
+                            !g.drop_thresh && (g.K % 4 == 0) && (g.lda % 4 == 0) && (g.ldb % 4 == 0) &&
+                            (reinterpret_cast<uintptr_t>(g.A) & 15) == 0 && (reinterpret_cast<uintptr_t>(g.B) & 15) == 0;
+    if (plain_rows) {
+        if (g.M <= 2) hipLaunchKernelGGL(gemv_rows_kernel<2>, dim3((g.N + 3) / 4), dim3(256), 0, st, g);
+        else hipLaunchKernelGGL(gemv_rows_kernel<8>, dim3((g.N + 3) / 4), dim3(256), 0, st, g);
+        return hipGetLastError();
+    }
     return launch_layout<float, float>(g, st);
 }
 

@@ -386,6 +386,18 @@ def test_gemm_layouts_and_ragged_shapes(M, N, K, akm, bkm, dtype):
     assert ((C.cpu().double() - ref).abs().max() / (ref.abs().max() + 1e-12)).item() < tol
 
 
+@pytest.mark.parametrize("M,N,K", [(2, 1536, 1024), (1, 7, 260), (8, 130, 512), (4, 512, 256)])
+def test_gemm_few_rows_fp32_conditioning_linears(M, N, K):
+    """M <= 8 fp32 rows (AdaLNModulation.linear, vit_components.py:131-147; time / context MLPs of diagnostic_losses.py:99-103,
+    132): the streaming row-vector path of hvc_gemm, with bias and alpha, against fp64."""
+    from hvc import ops
+    g = torch.Generator().manual_seed(M * 7 + N)
+    x, w, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g), torch.randn(N, generator=g)
+    ref = 0.5 * (x.double() @ w.double().t()) + b.double()
+    y = ops.gemm(x.to(dev()), w.to(dev()), bias=b.to(dev()), alpha=0.5)
+    assert y.shape == (M, N) and ((y.cpu().double() - ref).abs().max() / ref.abs().max()).item() < 1e-5
+
+
 def test_gemm_output_dropout_is_seeded_and_consistent_with_branch_bwd():
     from hvc import ops
     M, N, K = 256, 96, 64
