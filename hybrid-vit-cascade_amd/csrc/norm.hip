@@ -420,22 +420,35 @@ __global__ __launch_bounds__(256) void bn_relu_pool_bwd_apply_kernel(const T* __
                                                                       const PoolGeom pg, int training) {
     const int c8n = pg.C / 8;
     const int64_t total = (int64_t)pg.N * pg.H * pg.W * c8n;
+    // The grid stride is a multiple of C / 8 for the stems' power-of-two channel counts, so a thread keeps its 8 channels
+    // for the whole sweep and their coefficients are fetched once (otherwise they are re-fetched per element).
+    const bool fixed = ((int64_t)gridDim.x * 256) % c8n == 0;
+    float mean[8], rstd[8], gam[8], bet[8], m1[8], m2[8];
+    auto coeffs = [&](int c8) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = c8 * 8 + j;
+            mean[j] = stats[2 * c]; rstd[j] = stats[2 * c + 1];
+            gam[j] = gamma[c]; bet[j] = beta[c];
+            m1[j] = training ? cmean[2 * c] : 0.f; m2[j] = training ? cmean[2 * c + 1] : 0.f;
+        }
+    };
+    if (fixed) coeffs((int)(((int64_t)blockIdx.x * 256 + threadIdx.x) % c8n));
     for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
         const int c8 = (int)(idx % c8n);
         int64_t t = idx / c8n;
         const int w = (int)(t % pg.W); t /= pg.W;
         const int h = (int)(t % pg.H);
         const int n = (int)(t / pg.H);
+        if (!fixed) coeffs(c8);
         float xv[8], g[8], o[8];
         load8<T>(x + idx * 8, xv);
         pool_grad_gather<T>(dpool, amax, pg, n, h, w, c8, g);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int c = c8 * 8 + j;
-            const float rstd = stats[2 * c + 1];
-            const float xh = (xv[j] - stats[2 * c]) * rstd;
-            const float ds = (xh * gamma[c] + beta[c] > 0.f) ? g[j] : 0.f;
-            o[j] = training ? gamma[c] * rstd * (ds - cmean[2 * c] - xh * cmean[2 * c + 1]) : gamma[c] * rstd * ds;
+            const float xh = (xv[j] - mean[j]) * rstd[j];
+            const float ds = (xh * gam[j] + bet[j] > 0.f) ? g[j] : 0.f;
+            o[j] = gam[j] * rstd[j] * (ds - m1[j] - xh * m2[j]);      // eval mode: m1 = m2 = 0
         }
         store8<T>(dx + idx * 8, o);
     }
