@@ -187,16 +187,33 @@ __global__ __launch_bounds__(256) void gn_silu_fwd_kernel(const T* __restrict__ 
                                                            int B, int P, int C, int G, int act) {
     const int c8n = C / 8, cg = C / G;
     const int64_t total = (int64_t)B * P * c8n;
+    // a thread keeps its 8 channels for the whole sweep when the grid stride is a multiple of C / 8: affine parameters
+    // are fetched once; when its 8 channels lie in one group (C / G a multiple of 8) so are the statistics' addresses.
+    const bool fixed = ((int64_t)gridDim.x * 256) % c8n == 0;
+    const bool one_group = cg % 8 == 0;
+    float gam[8], bet[8];
+    auto coeffs = [&](int c8) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { gam[j] = gamma[c8 * 8 + j]; bet[j] = beta[c8 * 8 + j]; }
+    };
+    if (fixed) coeffs((int)(((int64_t)blockIdx.x * 256 + threadIdx.x) % c8n));
     for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
         const int c8 = (int)(idx % c8n);
         const int b = (int)(idx / ((int64_t)P * c8n));
+        if (!fixed) coeffs(c8);
         float v[8];
         load8<T>(x + idx * 8, v);
+        if (one_group) {
+            const int sg = b * G + (c8 * 8) / cg;
+            const float mean = stats[2 * sg], rstd = stats[2 * sg + 1];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int c = c8 * 8 + j, g = c / cg;
-            const float mean = stats[2 * (b * G + g)], rstd = stats[2 * (b * G + g) + 1];
-            v[j] = act_f((v[j] - mean) * rstd * gamma[c] + beta[c], act);
+            for (int j = 0; j < 8; ++j) v[j] = act_f((v[j] - mean) * rstd * gam[j] + bet[j], act);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int sg = b * G + (c8 * 8 + j) / cg;
+                v[j] = act_f((v[j] - stats[2 * sg]) * stats[2 * sg + 1] * gam[j] + bet[j], act);
+            }
         }
         store8<T>(y + idx * 8, v);
     }
@@ -270,19 +287,33 @@ __global__ __launch_bounds__(256) void gn_silu_bwd_apply_kernel(const T* __restr
     const int c8n = C / 8, cg = C / G;
     const float inv_n = 1.f / ((float)P * cg);
     const int64_t total = (int64_t)B * P * c8n;
+    const bool fixed = ((int64_t)gridDim.x * 256) % c8n == 0;       // see gn_silu_fwd_kernel
+    const bool one_group = cg % 8 == 0;
+    float gam[8], bet[8];
+    auto coeffs = [&](int c8) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { gam[j] = gamma[c8 * 8 + j]; bet[j] = beta[c8 * 8 + j]; }
+    };
+    if (fixed) coeffs((int)(((int64_t)blockIdx.x * 256 + threadIdx.x) % c8n));
     for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
         const int c8 = (int)(idx % c8n);
         const int b = (int)(idx / ((int64_t)P * c8n));
+        if (!fixed) coeffs(c8);
         float xv[8], dv[8], o[8];
         load8<T>(x + idx * 8, xv);
         load8<T>(dy + idx * 8, dv);
+        const int sg0 = b * G + (c8 * 8) / cg;
+        const float mean0 = stats[2 * sg0], rstd0 = stats[2 * sg0 + 1], g0 = gsum[2 * sg0], g1 = gsum[2 * sg0 + 1];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int c = c8 * 8 + j, g = c / cg, sg = b * G + g;
-            const float rstd = stats[2 * sg + 1];
-            const float xh = (xv[j] - stats[2 * sg]) * rstd;
-            const float ds = dv[j] * act_grad_f(xh * gamma[c] + beta[c], act);
-            o[j] = rstd * (ds * gamma[c] - (gsum[2 * sg] + xh * gsum[2 * sg + 1]) * inv_n);
+            float mean = mean0, rstd = rstd0, s0 = g0, s1 = g1;
+            if (!one_group) {
+                const int sg = b * G + (c8 * 8 + j) / cg;
+                mean = stats[2 * sg]; rstd = stats[2 * sg + 1]; s0 = gsum[2 * sg]; s1 = gsum[2 * sg + 1];
+            }
+            const float xh = (xv[j] - mean) * rstd;
+            const float ds = dv[j] * act_grad_f(xh * gam[j] + bet[j], act);
+            o[j] = rstd * (ds * gam[j] - (s0 + xh * s1) * inv_n);
         }
         store8<T>(dx + idx * 8, o);
     }
