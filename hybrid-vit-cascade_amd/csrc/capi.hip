@@ -295,7 +295,7 @@ int hvc_im2col(const void* src, void* col, int B, int C, int SD, int SH, int SW,
     int rc = fill_geom(g, B, C, SD, SH, SW, KD, KH, KW, stride, PD, PH, PW, OD, Kp);
     if (rc) return rc;
     if (!src || !col || !dtype_ok(dtype)) return fail(HVC_E_BADARG, "im2col: bad operand");
-    if (C % 8 == 0 && !(aligned16(src) && aligned16(col))) return fail(HVC_E_BADARG, "im2col: operands must be 16-byte aligned");
+    if (!aligned16(col) || (C % 8 == 0 && !aligned16(src))) return fail(HVC_E_BADARG, "im2col: operands must be 16-byte aligned");
     return hip_result(hvc::im2col_launch(g, src, col, dtype == HVC_BF16, (hipStream_t)stream), "im2col");
 }
 

@@ -54,20 +54,39 @@ __global__ __launch_bounds__(256) void im2col_kernel(const ConvGeom g, const T* 
             else { *reinterpret_cast<f32x4*>(dst) = v.a; *reinterpret_cast<f32x4*>(dst + 4) = v.b; }
         }
     } else {
-        const int64_t total = g.M * g.Kp;
+        // Few input channels (the stems' first convolutions, C = 1): one thread builds 8 consecutive k of a patch row,
+        // so the output position is decoded once per 16-byte store and the tap arithmetic stays 32-bit.
+        const int k8n = (int)(g.Kp / 8), kvalid = taps * g.C;
+        const int64_t total = g.M * k8n;
         for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
-            const int k = (int)(idx % g.Kp);
-            const int64_t m = idx / g.Kp;
-            float v = 0.f;
-            if (k < taps * g.C) {
-                const int c = k % g.C, tap = k / g.C;
-                const Pos o = decode(m, g.OD, g.OH, g.OW);
-                const int kw = tap % g.KW, kh = (tap / g.KW) % g.KH, kd = tap / (g.KW * g.KH);
-                const int sd = o.d * g.stride + kd - g.PD, sh = o.h * g.stride + kh - g.PH, sw = o.w * g.stride + kw - g.PW;
-                if (sd >= 0 && sd < g.SD && sh >= 0 && sh < g.SH && sw >= 0 && sw < g.SW)
-                    v = to_f<T>(src[((((int64_t)o.b * g.SD + sd) * g.SH + sh) * g.SW + sw) * g.C + c]);
+            const int k0 = (int)(idx % k8n) * 8;
+            const int64_t m = idx / k8n;
+            const Pos o = decode(m, g.OD, g.OH, g.OW);
+            const int64_t sb = (int64_t)o.b * g.SD;
+            const int d0 = o.d * g.stride - g.PD, h0 = o.h * g.stride - g.PH, w0 = o.w * g.stride - g.PW;
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = k0 + j;
+                v[j] = 0.f;
+                if (k < kvalid) {
+                    const int c = k % g.C, tap = k / g.C;
+                    const int kw = tap % g.KW, kh = (tap / g.KW) % g.KH, kd = tap / (g.KW * g.KH);
+                    const int sd = d0 + kd, sh = h0 + kh, sw = w0 + kw;
+                    if (sd >= 0 && sd < g.SD && sh >= 0 && sh < g.SH && sw >= 0 && sw < g.SW)
+                        v[j] = to_f<T>(src[(((sb + sd) * g.SH + sh) * g.SW + sw) * g.C + c]);
+                }
             }
-            col[idx] = from_f<T>(v);
+            T* dst = col + m * g.Kp + k0;
+            if constexpr (sizeof(T) == 2) {
+                bf16x8 w;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) w[j] = f2bf(v[j]);
+                *reinterpret_cast<bf16x8*>(dst) = w;
+            } else {
+                *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
+                *reinterpret_cast<f32x4*>(dst + 4) = f32x4{v[4], v[5], v[6], v[7]};
+            }
         }
     }
 }
@@ -244,7 +263,7 @@ int grid_for(int64_t work) {
 hipError_t im2col_launch(const ConvGeom& g, const void* src, void* col, int is_bf16, hipStream_t st) {
     const bool vec = (g.C % 8) == 0;
     const int taps = g.KD * g.KH * g.KW;
-    const int64_t work = vec ? g.M * taps * (g.C / 8) : g.M * g.Kp;
+    const int64_t work = vec ? g.M * taps * (g.C / 8) : g.M * (g.Kp / 8);
     dim3 grid(grid_for(work)), blk(256);
     if (is_bf16) {
         if (vec) hipLaunchKernelGGL((im2col_kernel<bf16, true>), grid, blk, 0, st, g, (const bf16*)src, (bf16*)col);
