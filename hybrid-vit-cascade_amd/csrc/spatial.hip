@@ -37,21 +37,26 @@ template <typename T, bool VEC>
 __global__ __launch_bounds__(256) void im2col_kernel(const ConvGeom g, const T* __restrict__ src, T* __restrict__ col) {
     const int taps = g.KD * g.KH * g.KW;
     if constexpr (VEC) {
-        const int c8n = g.C / 8;
-        const int64_t total = g.M * taps * c8n;
-        for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
-            const int c8 = (int)(idx % c8n);
-            const int tap = (int)((idx / c8n) % taps);
-            const int64_t m = idx / ((int64_t)c8n * taps);
+        // One wavefront per patch row: the output position is decoded once per row (64-bit divisions), the lanes walk the
+        // row's 16-byte chunks (tap, 8 channels) with 32-bit arithmetic; stores of a wavefront are one contiguous KiB.
+        const int c8n = g.C / 8, nchunk = taps * c8n;
+        const int lane = threadIdx.x & 63;
+        for (int64_t m = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); m < g.M; m += (int64_t)gridDim.x * 4) {
             const Pos o = decode(m, g.OD, g.OH, g.OW);
-            const int kw = tap % g.KW, kh = (tap / g.KW) % g.KH, kd = tap / (g.KW * g.KH);
-            const int sd = o.d * g.stride + kd - g.PD, sh = o.h * g.stride + kh - g.PH, sw = o.w * g.stride + kw - g.PW;
-            const bool ok = sd >= 0 && sd < g.SD && sh >= 0 && sh < g.SH && sw >= 0 && sw < g.SW;
-            Chunk8<T> v = zero_chunk<T>();
-            if (ok) v = load_chunk<T>(src + ((((int64_t)o.b * g.SD + sd) * g.SH + sh) * g.SW + sw) * g.C + c8 * 8, 8, true);
-            T* dst = col + m * g.Kp + (int64_t)tap * g.C + c8 * 8;
-            if constexpr (sizeof(T) == 2) *reinterpret_cast<bf16x8*>(dst) = v.v;
-            else { *reinterpret_cast<f32x4*>(dst) = v.a; *reinterpret_cast<f32x4*>(dst + 4) = v.b; }
+            const int64_t sb = (int64_t)o.b * g.SD;
+            const int d0 = o.d * g.stride - g.PD, h0 = o.h * g.stride - g.PH, w0 = o.w * g.stride - g.PW;
+            T* row = col + m * g.Kp;
+            for (int ch = lane; ch < nchunk; ch += 64) {
+                const int tap = ch / c8n, c8 = ch - tap * c8n;
+                const int kw = tap % g.KW, t2 = tap / g.KW, kh = t2 % g.KH, kd = t2 / g.KH;
+                const int sd = d0 + kd, sh = h0 + kh, sw = w0 + kw;
+                const bool ok = sd >= 0 && sd < g.SD && sh >= 0 && sh < g.SH && sw >= 0 && sw < g.SW;
+                Chunk8<T> v = zero_chunk<T>();
+                if (ok) v = load_chunk<T>(src + (((sb + sd) * g.SH + sh) * g.SW + sw) * g.C + c8 * 8, 8, true);
+                T* dst = row + ch * 8;
+                if constexpr (sizeof(T) == 2) *reinterpret_cast<bf16x8*>(dst) = v.v;
+                else { *reinterpret_cast<f32x4*>(dst) = v.a; *reinterpret_cast<f32x4*>(dst + 4) = v.b; }
+            }
         }
     } else {
         // Few input channels (the stems' first convolutions, C = 1): one thread builds 8 consecutive k of a patch row,
@@ -94,7 +99,6 @@ __global__ __launch_bounds__(256) void im2col_kernel(const ConvGeom g, const T* 
 // ---- col2im (gather form): dsrc[pos][c] = sum over (m, tap) with src(m, tap) == pos of dcol[m][tap*C + c] ----
 template <typename T, bool VEC>
 __global__ __launch_bounds__(256) void col2im_kernel(const ConvGeom g, const T* __restrict__ dcol, T* __restrict__ dsrc) {
-    const int taps = g.KD * g.KH * g.KW;
     constexpr int E = VEC ? 8 : 1;
     const int cn = g.C / E;
     const int64_t total = (int64_t)g.B * g.SD * g.SH * g.SW * cn;
@@ -262,8 +266,7 @@ int grid_for(int64_t work) {
 
 hipError_t im2col_launch(const ConvGeom& g, const void* src, void* col, int is_bf16, hipStream_t st) {
     const bool vec = (g.C % 8) == 0;
-    const int taps = g.KD * g.KH * g.KW;
-    const int64_t work = vec ? g.M * taps * (g.C / 8) : g.M * (g.Kp / 8);
+    const int64_t work = vec ? g.M * 64 : g.M * (g.Kp / 8);      // vec: one wavefront per patch row
     dim3 grid(grid_for(work)), blk(256);
     if (is_bf16) {
         if (vec) hipLaunchKernelGGL((im2col_kernel<bf16, true>), grid, blk, 0, st, g, (const bf16*)src, (bf16*)col);
