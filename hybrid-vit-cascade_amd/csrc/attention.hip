@@ -60,24 +60,21 @@ struct TileLoader {
     static constexpr int CHUNKS = kKT * CPR;           // per tile image
     static constexpr int CPT = CHUNKS / 256;           // chunks per thread
     Chunk8<T> reg[CPT];
-    const T* next[CPT];                                // this thread's chunk addresses in the next tile (VEC path)
-    int64_t step;                                      // elements between consecutive tiles
+    const T* next;                                     // this thread's first chunk in the next tile (VEC path)
+    int64_t step, rstep;                               // elements between consecutive tiles / between a thread's chunks
 
     // row0 = first row of the first tile this loader will be asked for; tiles are then requested in order.
     __device__ __forceinline__ void init(const T* base, int64_t sn, int row0, int tid) {
         step = (int64_t)kKT * sn;
-#pragma unroll
-        for (int i = 0; i < CPT; ++i) {
-            int c = tid + 256 * i;
-            next[i] = base + (int64_t)(row0 + c / CPR) * sn + (c % CPR) * 8;
-        }
+        rstep = (int64_t)(256 / CPR) * sn;             // chunk c of a thread sits 256 / CPR rows below chunk c - 1
+        next = base + (int64_t)(row0 + tid / CPR) * sn + (tid % CPR) * 8;
     }
     // Full tiles take the incremental addresses (one 64-bit add per chunk, no bounds selects); a ragged or
     // unaligned tile goes through the clamped / per-element path.
     __device__ __forceinline__ void issue(const T* base, int64_t sn, int row0, int nrows, int tid) {
         if (VEC && row0 + kKT <= nrows) {
 #pragma unroll
-            for (int i = 0; i < CPT; ++i) reg[i] = load_chunk<T>(next[i], 8, true);
+            for (int i = 0; i < CPT; ++i) reg[i] = load_chunk<T>(next + i * rstep, 8, true);
         } else {
 #pragma unroll
             for (int i = 0; i < CPT; ++i) {
@@ -86,8 +83,7 @@ struct TileLoader {
                 reg[i] = load_row_chunk<T, VEC>(base, sn, row0 + row, nrows, ch * 8);
             }
         }
-#pragma unroll
-        for (int i = 0; i < CPT; ++i) next[i] += step;
+        next += step;
     }
     // images: NS consecutive tiles of kKT*D bf16
     __device__ __forceinline__ void commit(bf16* images, int tid) {
