@@ -111,13 +111,14 @@ def attention_bwd(q, k, v, o, dout, lse, scale, p_drop=0.0, seed=0, dq=None, dk=
     if dout.shape != o.shape or dout.dtype != o.dtype:
         raise ValueError("attention_bwd: dout must match o")
     dout = dout.contiguous()
+    # gradients default to fresh buffers laid out like their primals (a strided view of a packed projection gets a
+    # buffer with the same gaps): the ABI gives dq/dk/dv the strides of q/k/v
     if dq is None:
-        dq = torch.empty_strided(q.shape, q.stride(), dtype=q.dtype, device=q.device) if _dense_like(q) else torch.empty_like(q, memory_format=torch.contiguous_format)
+        dq = torch.empty_strided(q.shape, q.stride(), dtype=q.dtype, device=q.device)
     if dk is None:
-        dk = torch.empty_strided(k.shape, k.stride(), dtype=k.dtype, device=k.device) if _dense_like(k) else torch.empty_like(k, memory_format=torch.contiguous_format)
+        dk = torch.empty_strided(k.shape, k.stride(), dtype=k.dtype, device=k.device)
     if dv is None:
-        dv = torch.empty_strided(v.shape, v.stride(), dtype=v.dtype, device=v.device) if _dense_like(v) else torch.empty_like(v, memory_format=torch.contiguous_format)
-    # the ABI gives dq/dk/dv the strides of q/k/v
+        dv = torch.empty_strided(v.shape, v.stride(), dtype=v.dtype, device=v.device)
     for g, x, n in ((dq, q, "dq"), (dk, k, "dk"), (dv, v, "dv")):
         if g.shape != x.shape or any(gs != xs for gs, xs, sz in zip(g.stride(), x.stride(), x.shape) if sz > 1):
             raise ValueError(f"attention_bwd: {n} must have the shape and strides of its primal")
@@ -140,10 +141,6 @@ def attention_bwd(q, k, v, o, dout, lse, scale, p_drop=0.0, seed=0, dq=None, dk=
         with _Timed("attn_bwd_dq_kernel", 1 * base):
             check(fn(*args, 4, _code(q.dtype), _stream()), "hvc_attention_bwd")
     return dq, dk, dv
-
-
-def _dense_like(t):
-    return t.is_contiguous()
 
 
 # --------------------------------------------------------------------------------------------

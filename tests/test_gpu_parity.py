@@ -274,6 +274,42 @@ def test_attention_kernel_edge_shapes(shape, dtype):
     assert rel(dv, vr.grad.permute(0, 2, 1, 3)) < tol
 
 
+@pytest.mark.parametrize("seed", range(8))
+def test_attention_random_shapes_and_packed_strides(seed):
+    """Randomised ragged shapes, with q/k/v read in place from a packed (B, N, 3, H, D) projection as the modules do
+    (vit_components.py:41-43) and gradients written into the packed buffer, fp32 and bf16, with dropout consistency
+    checked through linearity in V; odd sizes exercise the peeled ragged tile, the clamped loads and the tile parity logic."""
+    from hvc import ops
+    from oracle import hvc_oracle as O
+    rng = torch.Generator().manual_seed(1000 + seed)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=rng).item())
+    B, H, D = ri(1, 2), ri(1, 3), (32, 64)[seed % 2]
+    N = ri(1, 330)
+    dtype = (torch.float32, torch.bfloat16)[(seed // 2) % 2]
+    qkv = torch.randn(B, N, 3, H, D, generator=rng).to(dev(), dtype)
+    q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
+    qr, kr, vr = (t.float().cpu().permute(0, 2, 1, 3).requires_grad_(True) for t in (q, k, v))
+    o_ref = O.attention_core(qr, kr, vr, D ** -0.5)
+    do = torch.randn(B, N, H, D, generator=rng)
+    o_ref.backward(do.permute(0, 2, 1, 3))
+    o, lse = ops.attention_fwd(q, k, v, D ** -0.5)
+    dqkv = torch.empty_like(qkv)
+    ops.attention_bwd(q, k, v, o, do.to(dev(), dtype), lse, D ** -0.5, dq=dqkv[:, :, 0], dk=dqkv[:, :, 1], dv=dqkv[:, :, 2])
+    tol = F32_TOL if dtype == torch.float32 else 3e-2
+    rel = lambda a, b: ((a.float().cpu() - b).abs().max() / max(b.abs().max().item(), 1.0)).item()
+    assert rel(o, o_ref.permute(0, 2, 1, 3)) < tol, (B, H, N, D, dtype)
+    for i, ref in enumerate((qr.grad, kr.grad, vr.grad)):
+        assert rel(dqkv[:, :, i], ref.permute(0, 2, 1, 3)) < tol, (i, B, H, N, D, dtype)
+    # dropout on the same ragged shape: O is linear in V for a fixed seed, and <dO, O> = <dV, V>
+    p, sd = 0.3, 555 + seed
+    o1, lse1 = ops.attention_fwd(q, k, v, D ** -0.5, p, sd)
+    o2, _ = ops.attention_fwd(q, k, (2 * v.float()).to(dtype), D ** -0.5, p, sd)
+    assert rel(o2, 2 * o1.float().cpu()) < (1e-5 if dtype == torch.float32 else 2e-2)
+    _, _, dv = ops.attention_bwd(q, k, v, o1, do.to(dev(), dtype), lse1, D ** -0.5, p, sd)
+    lhs, rhs = (do.double() * o1.double().cpu()).sum().item(), (dv.double() * v.double()).sum().item()
+    assert abs(lhs - rhs) < (2e-3 if dtype == torch.float32 else 5e-2) * (abs(lhs) + abs(rhs) + 1.0)
+
+
 def test_attention_rejects_unsupported_head_dim():
     from hvc import ops
     q = torch.randn(1, 8, 1, 48, device=dev())
