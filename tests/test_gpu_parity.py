@@ -434,6 +434,55 @@ def test_gemm_few_rows_fp32_conditioning_linears(M, N, K):
     assert y.shape == (M, N) and ((y.cpu().double() - ref).abs().max() / ref.abs().max()).item() < 1e-5
 
 
+@pytest.mark.parametrize("seed", range(10))
+def test_gemm_fused_epilogues_random(seed):
+    """hvc_gemm's fused epilogue against fp64: alpha, bias, exact-erf GELU with the pre-activation saved (block MLP fc1,
+    hybrid_vit_backbone.py:74-81), GELU' multiply (its backward), z-save + AdaLN gate + fp32 residual (the gated residual
+    adds of :123 / :139), row-broadcast residual (pos_embed, :258), on ragged shapes and both operand dtypes."""
+    import torch.nn.functional as F
+    from hvc import ops
+    rng = torch.Generator().manual_seed(4000 + seed)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=rng).item())
+    nb = ri(1, 3)
+    rows = ri(1, 150)
+    M, N, K = nb * rows, ri(1, 40) * 8 if seed % 2 else ri(1, 300), ri(1, 40) * 8
+    dtype = (torch.float32, torch.bfloat16)[(seed // 2) % 2]
+    A = torch.randn(M, K, generator=rng).to(dtype)
+    W = torch.randn(N, K, generator=rng).to(dtype) / K ** 0.5
+    bias = torch.randn(N, generator=rng)
+    gate = torch.randn(nb, N, generator=rng)
+    res = torch.randn(M, N, generator=rng)
+    pos = torch.randn(rows, N, generator=rng)
+    pre_ref = 0.5 * (A.double() @ W.double().t()) + bias.double()
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    rel = lambda a, b: ((a.double().cpu() - b).abs().max() / max(b.abs().max().item(), 1e-6)).item()
+    d = lambda t: t.to(dev())
+    mode = seed % 5
+    if mode == 0:        # bias + GELU, pre-activation saved
+        aux = torch.empty(M, N, dtype=dtype, device=dev())
+        y = ops.gemm(d(A), d(W), alpha=0.5, bias=d(bias), act=ops.ACT_GELU, aux=aux)
+        assert rel(aux, pre_ref) < tol and rel(y, F.gelu(pre_ref)) < tol
+    elif mode == 1:      # GELU' multiply with a saved pre-activation
+        pre = torch.randn(M, N, generator=rng).to(dtype)
+        xr = pre.double().requires_grad_(True)
+        F.gelu(xr).sum().backward()
+        y = ops.gemm(d(A), d(W), alpha=0.5, act=ops.ACT_GELU_GRAD, aux=d(pre))
+        assert rel(y, (0.5 * (A.double() @ W.double().t())) * xr.grad) < tol
+    elif mode == 2:      # z-save, gate, residual -> fp32 residual stream
+        z = torch.empty(M, N, dtype=dtype, device=dev())
+        y = ops.gemm(d(A), d(W), alpha=0.5, bias=d(bias), zsave=z, gate=d(gate), residual=d(res), rows_per_batch=rows,
+                     out_dtype=torch.float32)
+        assert rel(z, pre_ref) < tol
+        assert rel(y, res.double() + pre_ref * gate.double().repeat_interleave(rows, 0)) < tol
+    elif mode == 3:      # row-broadcast residual (pos_embed added to every sample's tokens)
+        y = ops.gemm(d(A), d(W), alpha=0.5, bias=d(bias), residual=d(pos), residual_rows=rows, out_dtype=torch.float32)
+        assert rel(y, pre_ref + pos.double().repeat(nb, 1)) < tol
+    else:                # k-major operands with bias (dx / dW forms) into fp32
+        y = ops.gemm(d(A.t().contiguous()), d(W.t().contiguous()), a_kmajor=True, b_kmajor=True, alpha=0.5, bias=d(bias),
+                     out_dtype=torch.float32)
+        assert rel(y, pre_ref) < tol
+
+
 def test_gemm_output_dropout_is_seeded_and_consistent_with_branch_bwd():
     from hvc import ops
     M, N, K = 256, 96, 64
