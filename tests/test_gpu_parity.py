@@ -521,6 +521,56 @@ def test_layernorm_kernel_vs_oracle(C):
     assert torch.allclose(dx.cpu(), xr.grad, rtol=1e-3, atol=1e-4)
 
 
+@pytest.mark.parametrize("seed", range(10))
+def test_layernorm_and_row_kernels_random(seed):
+    """LayerNorm (+AdaLN modulate) forward / backward with every output (dx incl. the residual-stream gradient, dgamma,
+    dbeta, dscale, dshift), the residual-branch backward (dz, dgate, dbias) and the column sum, on random ragged shapes:
+    both the 4-values-per-lane (C <= 256) and the wide instantiation, vector and scalar column paths."""
+    import torch.nn.functional as F
+    from hvc import ops
+    rng = torch.Generator().manual_seed(7000 + seed)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=rng).item())
+    nb, rows = ri(1, 3), ri(1, 200)
+    C = (ri(1, 64) * 4, ri(1, 256), ri(65, 256) * 4, 256, 1024)[seed % 5]
+    mod = seed % 2 == 0
+    dy_dtype = (torch.float32, torch.bfloat16)[(seed // 5) % 2]
+    M = nb * rows
+    x = (torch.randn(M, C, generator=rng) * 2 + 0.5).double().requires_grad_(True)
+    gam = torch.randn(C, generator=rng).double().requires_grad_(True)
+    bet = torch.randn(C, generator=rng).double().requires_grad_(True)
+    sc = (torch.randn(nb, C, generator=rng) * 0.3).double().requires_grad_(True)
+    sh = torch.randn(nb, C, generator=rng).double().requires_grad_(True)
+    y = F.layer_norm(x, (C,), gam, bet, 1e-5)
+    if mod:
+        y = y.view(nb, rows, C) * (1 + sc[:, None]) + sh[:, None]
+    dy = torch.randn(M, C, generator=rng).to(dy_dtype)
+    dres = torch.randn(M, C, generator=rng)
+    y.reshape(M, C).backward(dy.double())
+    d = lambda t: None if t is None else t.detach().float().to(dev())
+    yk, mean, rstd = ops.layernorm_fwd(d(x), d(gam), d(bet), d(sc) if mod else None, d(sh) if mod else None, rows_per_batch=rows)
+    rel = lambda a, b: ((a.double().cpu() - b).abs().max() / max(b.abs().max().item(), 1e-3)).item()
+    assert rel(yk, y.reshape(M, C).detach()) < 1e-5
+    outs = ops.layernorm_bwd(dy.to(dev()), d(x), d(gam), d(bet), d(sc) if mod else None, mean, rstd, dres=dres.to(dev()), rows_per_batch=rows)
+    tol = 2e-5 if dy_dtype == torch.float32 else 2e-5      # dy is the same rounded tensor on both sides
+    assert rel(outs[0], x.grad + dres.double()) < tol
+    assert rel(outs[1], gam.grad) < 1e-4 and rel(outs[2], bet.grad) < 1e-4
+    if mod:
+        assert rel(outs[3], sc.grad) < 1e-4 and rel(outs[4], sh.grad) < 1e-4
+    else:
+        assert outs[3] is None and outs[4] is None
+    # residual-branch backward and column sum
+    N = C
+    g2 = torch.randn(M, N, generator=rng)
+    z = torch.randn(M, N, generator=rng).to(dy_dtype)
+    gate = torch.randn(nb, N, generator=rng)
+    dz, dgate, dbias = ops.branch_bwd(g2.to(dev()), z.to(dev()), gate.to(dev()), rows_per_batch=rows, out_dtype=dy_dtype)
+    v = g2.double() * gate.double().repeat_interleave(rows, 0)
+    assert rel(dz, v) < (1e-6 if dy_dtype == torch.float32 else 1e-2)
+    assert rel(dgate, (g2.double() * z.double()).view(nb, rows, N).sum(1)) < 1e-4
+    assert rel(dbias, v.sum(0)) < 1e-4
+    assert rel(ops.colsum(z.to(dev())), z.double().sum(0)) < 1e-4
+
+
 def test_layernorm_rejects_wide_rows():
     from hvc import ops
     x = torch.randn(4, 2048, device=dev())
