@@ -571,6 +571,59 @@ def test_layernorm_and_row_kernels_random(seed):
     assert rel(ops.colsum(z.to(dev())), z.double().sum(0)) < 1e-4
 
 
+@pytest.mark.parametrize("seed", range(8))
+def test_groupnorm_and_batchnorm_pool_kernels_random(seed):
+    """GroupNorm + SiLU / GELU (voxel stem hybrid_vit_backbone.py:195-210, cascade glue model_progressive.py:37-51, 169-174) and
+    BatchNorm2d + ReLU + MaxPool2d (X-ray stem diagnostic_losses.py:82-96) on channels-last tensors of random shape
+    against ATen: outputs, running statistics, input and parameter gradients, train and eval mode."""
+    import torch.nn.functional as F
+    from hvc import functional as HF, ops
+    rng = torch.Generator().manual_seed(9000 + seed)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=rng).item())
+    rel = lambda a, b: ((a.double().cpu() - b).abs().max() / max(b.abs().max().item(), 1e-3)).item()
+    # ---- GroupNorm + activation on (B, D, H, W, C)
+    C = (8, 16, 32, 64, 128, 256, 64, 32)[seed]
+    G = (8, 8, 8, 8, 16, 32, 16, 32)[seed]            # incl. one channel per group
+    B, sp = ri(1, 3), (ri(1, 5), ri(1, 6), ri(1, 7))
+    act = seed % 2
+    x = torch.randn(B, *sp, C, generator=rng) * 1.5 + 0.3
+    gam, bet = torch.randn(C, generator=rng), torch.randn(C, generator=rng)
+    dy = torch.randn(B, *sp, C, generator=rng)
+    xr, gr, br = (t.double().requires_grad_(True) for t in (x, gam, bet))
+    yn = F.group_norm(xr.permute(0, 4, 1, 2, 3), G, gr, br, 1e-5)
+    yr = (F.silu(yn) if act == 0 else F.gelu(yn)).permute(0, 2, 3, 4, 1)
+    yr.backward(dy.double())
+    xg, gg, bg = (t.to(dev()).requires_grad_(True) for t in (x, gam, bet))
+    y = HF.GroupNormSiluFn.apply(xg, gg, bg, G, 1e-5, act)
+    y.backward(dy.to(dev()))
+    assert rel(y.detach(), yr.detach()) < 2e-5 and rel(xg.grad, xr.grad) < 1e-4
+    assert rel(gg.grad, gr.grad) < 1e-4 and rel(bg.grad, br.grad) < 1e-4
+    # ---- BatchNorm + ReLU + MaxPool on (N, H, W, C)
+    Cb = (8, 64, 128, 16, 64, 512, 8, 128)[seed]
+    pool = (None, (3, 2, 1), (2, 2, 0), (3, 2, 1), None, None, (2, 2, 0), (3, 2, 1))[seed]
+    N, Hh, Ww = ri(1, 4), ri(2, 17), ri(2, 19)
+    training = seed % 3 != 0
+    x = torch.randn(N, Hh, Ww, Cb, generator=rng) * 2 - 0.4
+    gam, bet = torch.rand(Cb, generator=rng) + 0.5, torch.randn(Cb, generator=rng) * 0.5
+    rm, rv = torch.randn(Cb, generator=rng) * 0.1, torch.rand(Cb, generator=rng) + 0.5
+    xr, gr, br = (t.double().requires_grad_(True) for t in (x, gam, bet))
+    rm_r, rv_r = rm.double().clone(), rv.double().clone()
+    yb = F.relu(F.batch_norm(xr.permute(0, 3, 1, 2), rm_r, rv_r, gr, br, training, 0.1, 1e-5))
+    if pool:
+        yb = F.max_pool2d(yb, pool[0], pool[1], pool[2])
+    yb = yb.permute(0, 2, 3, 1)
+    dy = torch.randn(*yb.shape, generator=rng)
+    yb.backward(dy.double())
+    xg, gg, bg = (t.to(dev()).requires_grad_(True) for t in (x, gam, bet))
+    rm_g, rv_g = rm.to(dev()), rv.to(dev())
+    y = HF.BnReluPoolFn.apply(xg, gg, bg, rm_g, rv_g, pool, training, 1e-5, 0.1)
+    y.backward(dy.to(dev()))
+    assert y.shape == yb.shape and rel(y.detach(), yb.detach()) < 2e-5
+    assert rel(rm_g, rm_r) < 1e-5 and rel(rv_g, rv_r) < 1e-5
+    # ReLU / max ties are measure-zero for random data: gradients must agree element-wise
+    assert rel(xg.grad, xr.grad) < 1e-4 and rel(gg.grad, gr.grad) < 1e-4 and rel(bg.grad, br.grad) < 1e-4
+
+
 def test_layernorm_rejects_wide_rows():
     from hvc import ops
     x = torch.randn(4, 2048, device=dev())
