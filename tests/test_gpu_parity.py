@@ -1048,3 +1048,54 @@ def test_conv_slabbed_equals_whole_and_oracle(cfg, dtype):
             assert ((a.double() - r).abs().max() / (r.abs().max() + 1e-12)).item() < tol
     for a, c in zip(*results):       # slab-wise vs single shot: same products, only the dW summation order differs
         assert torch.allclose(a, c, rtol=1e-3 if dtype == torch.float32 else 2e-2, atol=1e-4 if dtype == torch.float32 else 2e-2)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_conv_layers_random_geometry(seed):
+    """nn.Conv2d / nn.Conv3d through hvc.stem.conv_channels_last (im2col + MFMA GEMM, col2im, split-K wgrad) against ATen on
+    random geometry: kernel 1 / 3 / 5 / 7, stride 1 / 2, asymmetric extents, channel counts on both im2col paths (C % 8 == 0 and
+    few-channel), fp32 and bf16 - the stems of diagnostic_losses.py:82-96, hybrid_vit_backbone.py:195-210 and
+    model_progressive.py:259-267 (incl. its 1x1x1 convolution)."""
+    import torch.nn as nn
+    from hvc import stem
+    rng = torch.Generator().manual_seed(12000 + seed)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=rng).item())
+    is3d = seed % 3 != 0
+    k = (1, 3, 3, 7, 5, 3, 1, 3, 7, 3)[seed]
+    stride = (1, 2, 1, 2, 1, 2, 1, 1, 2, 2)[seed]
+    pad = k // 2 if seed % 4 else 0
+    cin = (1, 8, 3, 1, 16, 32, 64, 2, 5, 24)[seed]
+    cout = (7, 16, 32, 64, 9, 24, 1, 33, 8, 40)[seed]
+    B = ri(1, 2)
+    sp = tuple(ri(max(k, 2), 13) for _ in range(3 if is3d else 2))
+    dtype = (torch.float32, torch.bfloat16)[(seed // 5) % 2]
+    torch.manual_seed(seed)
+    layer = (nn.Conv3d if is3d else nn.Conv2d)(cin, cout, k, stride=stride, padding=pad)
+    x = torch.randn(B, cin, *sp, generator=rng)
+    ref_layer = (nn.Conv3d if is3d else nn.Conv2d)(cin, cout, k, stride=stride, padding=pad).double()
+    ref_layer.load_state_dict({n: (t.to(dtype).double() if dtype == torch.bfloat16 else t.double()) for n, t in layer.state_dict().items()})
+    xr = x.to(dtype).double().requires_grad_(True)
+    yr = ref_layer(xr)
+    dy = torch.randn(yr.shape, generator=rng)
+    yr.backward(dy.to(dtype).double())
+    layer.to(dev())
+    perm_in = (0, 2, 3, 4, 1) if is3d else (0, 2, 3, 1)
+    h = x.to(dev()).to(dtype).permute(*perm_in).contiguous()
+    if not is3d:
+        h = h.unsqueeze(1)                                          # (B, 1, H, W, C): the 2-D convolutions run as depth-1 volumes
+    h.requires_grad_(True)
+    y = stem.conv_channels_last(h, layer, dtype)
+    dyc = dy.to(dev()).to(dtype).permute(*perm_in)
+    if not is3d:
+        dyc = dyc.unsqueeze(1)
+    (y.float() * dyc.float()).sum().backward()
+    back = (0, 4, 1, 2, 3)
+    got_y = y.detach().permute(*back).float().cpu()
+    got_dx = h.grad.permute(*back).float().cpu()
+    if not is3d:
+        got_y, got_dx = got_y.squeeze(2), got_dx.squeeze(2)
+    tol = 1e-4 if dtype == torch.float32 else 2.5e-2
+    rel = lambda a, b: ((a.double() - b).abs().max() / (b.abs().max() + 1e-9)).item()
+    assert got_y.shape == yr.shape and rel(got_y, yr.detach()) < tol
+    assert rel(got_dx, xr.grad) < tol
+    assert rel(layer.weight.grad.cpu(), ref_layer.weight.grad) < tol and rel(layer.bias.grad.cpu(), ref_layer.bias.grad) < tol
