@@ -40,10 +40,18 @@ class DirectCTRegression(nn.Module):
         return self.vit_backbone(x=x, context=feats.flatten(2).transpose(1, 2), cond=cond, prev_stage_embed=None)
 
 
+def _check_window_fits(pred, window_size):
+    # F.avg_pool3d (reference :92) rejects an input extent below the kernel size even when the padding would cover it
+    if min(pred.shape[-3:]) < window_size:
+        raise RuntimeError(f"input image (T: {pred.shape[-3]} H: {pred.shape[-2]} W: {pred.shape[-1]}) smaller than kernel size "
+                           f"(kT: {window_size} kH: {window_size} kW: {window_size})")
+
+
 def compute_ssim_loss(pred, target, window_size=11):
     """1 - mean SSIM with a window_size^3 zero-padded box window (reference :88-107), fused HIP kernel."""
     if not pred.is_cuda:
         raise RuntimeError("compute_ssim_loss runs on the MI355X HIP path only (no CPU fallback)")
+    _check_window_fits(pred, int(window_size))
     return HF.SsimL1LossFn.apply(pred, target, 0.0, 1.0, int(window_size))[2]
 
 
@@ -56,5 +64,6 @@ class DirectRegressionLoss(nn.Module):
     def forward(self, pred, target):
         if not pred.is_cuda:
             raise RuntimeError("DirectRegressionLoss runs on the MI355X HIP path only (no CPU fallback)")
+        _check_window_fits(pred, 11)
         out = HF.SsimL1LossFn.apply(pred, target, float(self.l1_weight), float(self.ssim_weight), 11)
         return {"total_loss": out[0], "l1_loss": out[1], "ssim_loss": out[2]}

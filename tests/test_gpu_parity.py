@@ -1099,3 +1099,34 @@ def test_conv_layers_random_geometry(seed):
     assert got_y.shape == yr.shape and rel(got_y, yr.detach()) < tol
     assert rel(got_dx, xr.grad) < tol
     assert rel(layer.weight.grad.cpu(), ref_layer.weight.grad) < tol and rel(layer.bias.grad.cpu(), ref_layer.bias.grad) < tol
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_ssim_l1_loss_random_sizes_and_weights(seed):
+    """DirectRegressionLoss (model_direct.py:69-133) at random non-cubic volume sizes from the 11-voxel window upwards, random
+    loss weights and value ranges: the three loss terms and d(total)/d(pred) against the oracle's autograd; an extent below
+    the window is the RuntimeError F.avg_pool3d raises in the reference."""
+    from direct_regression.model_direct import DirectRegressionLoss
+    from oracle import hvc_oracle as O
+    gen = torch.Generator().manual_seed(13000 + seed)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=gen).item())
+    B = ri(1, 3)
+    size = (ri(11, 29), ri(11, 29), ri(11, 40)) if seed else (11, 11, 11)
+    wl1, wss = (1.0, 0.5) if seed % 2 else (float(torch.rand(1, generator=gen)) + 0.1, float(torch.rand(1, generator=gen)) + 0.1)
+    amp = (1.0, 0.05, 3.0, 1.0)[seed % 4]
+    t = (torch.rand(B, 1, *size, generator=gen) * 2 - 1) * amp
+    p = (t * float(torch.rand(1, generator=gen)) + torch.randn(B, 1, *size, generator=gen) * 0.3 * amp)
+    pr = p.clone().requires_grad_(True)
+    ref = O.direct_regression_loss(pr, t, l1_weight=wl1, ssim_weight=wss)
+    ref["total_loss"].backward()
+    pg = p.to(dev()).requires_grad_(True)
+    got = DirectRegressionLoss(wl1, wss)(pg, t.to(dev()))
+    got["total_loss"].backward()
+    for k in ("total_loss", "l1_loss", "ssim_loss"):
+        assert abs(got[k].item() - ref[k].item()) < 1e-5 * max(1.0, abs(ref[k].item())), (k, got[k].item(), ref[k].item())
+    err = (pg.grad.cpu() - pr.grad).norm() / pr.grad.norm()
+    assert err < 1e-3, err
+    if seed == 0:
+        small = torch.zeros(1, 1, 9, 12, 12, device=dev())
+        with pytest.raises(RuntimeError, match="smaller than kernel size"):
+            DirectRegressionLoss()(small, small)
