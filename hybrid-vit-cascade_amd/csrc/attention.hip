@@ -23,6 +23,7 @@
 //            64-query tiles (Q, dO in LDS, read row-wise for S / dP and transposed for dV / dK).
 // The split backward recomputes S twice (7 products instead of 5) in exchange for having no
 // cross-workgroup reduction: dQ, dK, dV are bitwise reproducible.
+#include <cstdlib>
 #include <type_traits>
 
 #include "hvc_common.hip.h"
@@ -415,6 +416,225 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 3 : 2) void attn_fwd_kernel(c
                 }
             }
         if (h == 0) a.lse[(int64_t)bh * a.Nq + qrow] = (msc + __builtin_amdgcn_logf(ltot)) * kLn2;
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// forward, 64 query rows per wavefront (bf16, 16-byte addressable operands)
+// ---------------------------------------------------------------------------------
+// Same decomposition as attn_fwd_kernel with two 32-row query blocks per wavefront and 32-key LDS tiles: every K row
+// fragment and transposed V fragment read from LDS feeds two MFMAs (one per query block), and a workgroup's K/V tile
+// traffic (global loads, LDS writes, barrier) is shared by 256 query rows instead of 128.  Per 16 MFMAs: 12 LDS
+// fragment reads instead of 24, 2 tile-chunk loads per thread instead of 4.  Dropout lots are the same function of
+// (row, key) as everywhere else: a 32-key tile t is half t & 1 of the 64-key hash tile t >> 1.
+constexpr int kQB2 = 256, kKT2 = 32;
+
+template <int D, bool DROP>
+__global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const AttnArgs a) {
+    using T = bf16;
+    constexpr int TILE = kKT2 * D;
+    constexpr int CPR = D / 8;                         // 16-byte chunks per tile row
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16* lds = reinterpret_cast<bf16*>(smem);         // [buf][K|V][TILE]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+
+    const int nqb = (a.Nq + kQB2 - 1) / kQB2;
+    int bh, qb;
+    block_map(blockIdx.x, a.B * a.H, nqb, bh, qb);
+    const int b = bh / a.H, hh = bh % a.H;
+    const T* qp = reinterpret_cast<const T*>(a.q) + b * a.q_sb + hh * a.q_sh;
+    const T* kp = reinterpret_cast<const T*>(a.k) + b * a.k_sb + hh * a.k_sh;
+    const T* vp = reinterpret_cast<const T*>(a.v) + b * a.v_sb + hh * a.v_sh;
+    T* op = reinterpret_cast<T*>(a.o) + b * a.o_sb + hh * a.o_sh;
+
+    const int q0 = qb * kQB2 + wave * 64;
+    const float sl2 = a.scale * kLog2e;
+    int qrow[2];
+    bool qvalid[2];
+    bf16x8 qf[2][1][D / 16];
+    uint32_t rowkey[2];
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+        qrow[blk] = q0 + 32 * blk + r;
+        qvalid[blk] = qrow[blk] < a.Nq;
+        const int qc = qvalid[blk] ? qrow[blk] : a.Nq - 1;
+        load_row_frags_scaled<T, 1, D / 16, true>(qp + (int64_t)qc * a.q_sn, h, true, sl2, qf[blk]);
+        rowkey[blk] = DROP ? drop_rowkey(a, bh, qc) ^ (h ? kGrpH : 0u) : 0u;
+    }
+    const uint32_t tm1x2 = DROP ? ((uint32_t)(drop_ts(a) - 1) & 0xffffu) * 0x10001u : 0u;
+
+    // tile loader: one 16-byte chunk of K and of V per thread (D = 32: the first 128 threads)
+    const int lrow = tid / CPR, lch = tid % CPR;
+    const bool lactive = lrow < kKT2;
+    const T* knext = kp + (int64_t)lrow * a.k_sn + lch * 8;
+    const T* vnext = vp + (int64_t)lrow * a.v_sn + lch * 8;
+    const int64_t kstep = (int64_t)kKT2 * a.k_sn, vstep = (int64_t)kKT2 * a.v_sn;
+    Chunk8<T> kreg, vreg;
+    auto issue = [&](int row0) {
+        if (lactive) {
+            if (row0 + kKT2 <= a.Nk) {
+                kreg = load_chunk<T>(knext, 8, true);
+                vreg = load_chunk<T>(vnext, 8, true);
+            } else {
+                kreg = load_row_chunk<T, true>(kp, a.k_sn, row0 + lrow, a.Nk, lch * 8);
+                vreg = load_row_chunk<T, true>(vp, a.v_sn, row0 + lrow, a.Nk, lch * 8);
+            }
+        }
+        knext += kstep;
+        vnext += vstep;
+    };
+    auto commit = [&](int buf) {
+        if (lactive) {
+            bf16x8 im[1];
+            chunk_split<T>(kreg, im);
+            tile_store<D>(lds + (buf * 2 + 0) * TILE, lrow, lch, im[0]);
+            chunk_split<T>(vreg, im);
+            tile_store<D>(lds + (buf * 2 + 1) * TILE, lrow, lch, im[0]);
+        }
+    };
+
+    const int nt = (a.Nk + kKT2 - 1) / kKT2;
+    issue(0);
+    commit(0);
+    __syncthreads();
+
+    float msc[2] = {0.f, 0.f}, l[2] = {0.f, 0.f};
+    f32x16 negm[2], o[2][D / 32];
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) negm[blk][i] = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < D / 32; ++dt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) o[blk][dt][i] = 0.f;
+    }
+    const bf16* kaddr[D / 16];
+    const bf16* vaddr[D / 32][2];
+#pragma unroll
+    for (int s = 0; s < D / 16; ++s) kaddr[s] = lds + row_frag_lane_off<D>(16 * s, lane);
+#pragma unroll
+    for (int dt = 0; dt < D / 32; ++dt) {
+        int oa, ob;
+        tr_frag_lane_off<D, true>(32 * dt, lane, oa, ob);
+        vaddr[dt][0] = lds + oa;
+        vaddr[dt][1] = lds + ob;
+    }
+
+    auto tile = [&](auto mask_tag, auto buf_tag, int t) {
+        constexpr bool MASK = decltype(mask_tag)::value;
+        constexpr int buf = decltype(buf_tag)::value;            // = t & 1 = which half of the 64-key hash tile
+        constexpr int KOFF = (buf * 2 + 0) * TILE, VOFF = (buf * 2 + 1) * TILE;
+        f32x16 st[2] = {negm[0], negm[1]};
+#pragma unroll
+        for (int s = 0; s < D / 16; ++s) {
+            const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kaddr[s] + KOFF);
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk) st[blk] = mfma32(kf, qf[blk][0][s], st[blk]);
+        }
+        if (t + 1 < nt) issue((t + 1) * kKT2);      // after the score chain: the staging registers are idle until the commit
+        if constexpr (MASK) {
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    if (t * kKT2 + acc_row(i, h) >= a.Nk) st[blk][i] = -INFINITY;
+        }
+        float mloc[2];
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+            float m = -INFINITY;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) m = fmaxf(m, st[blk][i]);
+            mloc[blk] = fmaxf(m, __shfl_xor(m, 32, 64));
+        }
+        if (t == 0 || __any(fmaxf(mloc[0], mloc[1]) > kRescaleLog2)) {
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk) {
+                const float shift = t == 0 ? mloc[blk] : fmaxf(mloc[blk], 0.f);
+                const float alpha = t == 0 ? 1.f : __builtin_amdgcn_exp2f(-shift);
+                l[blk] *= alpha;
+#pragma unroll
+                for (int dt = 0; dt < D / 32; ++dt)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) o[blk][dt][i] *= alpha;
+                msc[blk] += shift;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) negm[blk][i] = -msc[blk];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) st[blk][i] -= shift;
+            }
+        }
+        // O^T[d][q] += V^T P^T: each transposed V fragment serves both query blocks
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            bf16x8 vfr[D / 32];
+#pragma unroll
+            for (int dt = 0; dt < D / 32; ++dt) vfr[dt] = tr_frag_at(vaddr[dt][0] + (VOFF + 16 * s2 * D), vaddr[dt][1] + (VOFF + 16 * s2 * D));
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk) {
+                float x[8], rs = 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    x[j] = __builtin_amdgcn_exp2f(st[blk][8 * s2 + j]);
+                    rs += x[j];
+                }
+                l[blk] += rs;
+                bf16x8 pf[1];
+                acc_split<1>(x, pf);
+                if constexpr (DROP) {
+                    const uint32_t rk_tile = rowkey[blk] + (uint32_t)(t >> 1) * kTileAdd;
+#pragma unroll
+                    for (int g2 = 0; g2 < 2; ++g2) {      // group j = 8 buf + 2 (2 s2 + g2) + h of hash tile t >> 1
+                        const uint32_t m = rk_tile ^ (drop_grp_a(buf) ^ drop_grp_b(2 * s2 + g2));
+                        const uint32_t ma = drop_keepmask2(drop_lots(m, kLotMulA), tm1x2);
+                        const uint32_t mb = drop_keepmask2(drop_lots(m, kLotMulB), tm1x2);
+                        u32x4 w = __builtin_bit_cast(u32x4, pf[0]);
+                        w[2 * g2] &= ma;
+                        w[2 * g2 + 1] &= mb;
+                        pf[0] = __builtin_bit_cast(bf16x8, w);
+                    }
+                }
+#pragma unroll
+                for (int dt = 0; dt < D / 32; ++dt) o[blk][dt] = mfma32(vfr[dt], pf[0], o[blk][dt]);
+            }
+        }
+        if (t + 1 < nt) commit(buf ^ 1);
+        __syncthreads();
+    };
+    const bool ragged = (a.Nk % kKT2) != 0;
+    const int nfull = ragged ? nt - 1 : nt;
+    using B0 = std::integral_constant<int, 0>;
+    using B1 = std::integral_constant<int, 1>;
+    int t = 0;
+    for (; t + 1 < nfull; t += 2) {
+        tile(std::false_type{}, B0{}, t);
+        tile(std::false_type{}, B1{}, t + 1);
+    }
+    if (t < nfull) tile(std::false_type{}, B0{}, t);            // t is even here
+    if (ragged) {
+        if ((nt - 1) & 1) tile(std::true_type{}, B1{}, nt - 1);
+        else tile(std::true_type{}, B0{}, nt - 1);
+    }
+
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+        const float ltot = l[blk] + __shfl_xor(l[blk], 32, 64);
+        const float inv = (DROP ? a.keep_scale : 1.f) / ltot;
+        if (qvalid[blk]) {
+            T* orow = op + (int64_t)qrow[blk] * a.o_sn;
+#pragma unroll
+            for (int dt = 0; dt < D / 32; ++dt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    bf16x4 w;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) w[j] = f2bf(o[blk][dt][4 * g + j] * inv);
+                    *reinterpret_cast<bf16x4*>(orow + 32 * dt + 8 * g + 4 * h) = w;
+                }
+            if (h == 0) a.lse[(int64_t)bh * a.Nq + qrow[blk]] = (msc[blk] + __builtin_amdgcn_logf(ltot)) * kLn2;
+        }
     }
 }
 
@@ -903,6 +1123,18 @@ hipError_t set_lds(K kernel, size_t bytes) {
 
 template <typename T, int D, bool DROP, bool VEC>
 hipError_t launch_fwd(const AttnArgs& a, hipStream_t st) {
+    if constexpr (sizeof(T) == 2 && VEC) {
+        // 64 rows per wavefront once its 256-row workgroups fill every CU twice over; smaller problems keep the 128-row
+        // workgroups (more of them, three per CU)
+        const int nqb2 = (a.Nq + kQB2 - 1) / kQB2;
+        const char* env = getenv("HVC_ATTN_FWD_ROWS");          // "64" / "32": pin the kernel (parity tests run both on every shape)
+        const int force = env ? atoi(env) : 0;
+        if (force == 64 || (force != 32 && nqb2 * a.B * a.H >= 512)) {
+            const size_t lds2 = (size_t)2 * 2 * kKT2 * D * sizeof(bf16);
+            hipLaunchKernelGGL((attn_fwd2_kernel<D, DROP>), dim3(nqb2 * a.B * a.H), dim3(256), lds2, st, a);
+            return hipGetLastError();
+        }
+    }
     const int nqb = (a.Nq + kQB - 1) / kQB;
     const size_t lds = fwd_lds_bytes<T, D>();
     auto k = attn_fwd_kernel<T, D, DROP, VEC>;

@@ -12,11 +12,12 @@ B, H, N, M, D = 2, 4, 32768, 32768, 64
 q = torch.randn(B, N, H, D, device=dev, dtype=torch.bfloat16); k = torch.randn(B, M, H, D, device=dev, dtype=torch.bfloat16); v = torch.randn_like(k)
 for p in (0.0, 0.1):
     o, lse = ops.attention_fwd(q, k, v, D ** -0.5, p, 7); do = torch.randn_like(o)
-    for _ in range(2): ops.attention_bwd(q, k, v, o, do, lse, D ** -0.5, p, 7)
+    fwd_only = os.environ.get("ATTN_AB_FWD_ONLY") == "1"
+    for _ in range(2): fwd_only or ops.attention_bwd(q, k, v, o, do, lse, D ** -0.5, p, 7)
     ops.PROFILE = []
     for _ in range(6):
         with ops._Timed("attn_fwd_kernel", 0): ops.attention_fwd(q, k, v, D ** -0.5, p, 7)
-        ops.attention_bwd(q, k, v, o, do, lse, D ** -0.5, p, 7)
+        fwd_only or ops.attention_bwd(q, k, v, o, do, lse, D ** -0.5, p, 7)
     torch.cuda.synchronize()
     acc = {}
     for name, w, s, e in ops.PROFILE: acc.setdefault(name, []).append(s.elapsed_time(e))

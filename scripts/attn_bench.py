@@ -21,6 +21,8 @@ def split(fn, n):
 shapes = ((2, 4, 32768, 32768, 64), (2, 4, 32768, 4096, 64), (4, 4, 4096, 4096, 64), (2, 8, 32768, 32768, 32))
 if len(sys.argv) > 1 and sys.argv[1] == "quick":
     shapes = shapes[:1]
+if len(sys.argv) > 1 and sys.argv[1] == "cross":
+    shapes = shapes[1:2]
 for (B, H, N, M, D) in shapes:
     q = torch.randn(B, N, H, D, device=dev, dtype=torch.bfloat16); k = torch.randn(B, M, H, D, device=dev, dtype=torch.bfloat16); v = torch.randn_like(k)
     for p in (0.0, 0.1):

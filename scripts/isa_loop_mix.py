@@ -3,7 +3,7 @@ import re, sys
 from collections import Counter
 path, needle = sys.argv[1], sys.argv[2]
 lines = open(path).read().split("\n")
-start = next(i for i, l in enumerate(lines) if l.startswith("_ZN") and needle in l and l.rstrip().split(":")[0].endswith("E") )
+start = next(i for i, l in enumerate(lines) if l.startswith("_ZN") and needle in l and ":" in l )
 end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
 blocks, cur, lab = [], [], "entry"
 for l in lines[start + 1:end]:

@@ -1130,3 +1130,50 @@ def test_ssim_l1_loss_random_sizes_and_weights(seed):
         small = torch.zeros(1, 1, 9, 12, 12, device=dev())
         with pytest.raises(RuntimeError, match="smaller than kernel size"):
             DirectRegressionLoss()(small, small)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_attention_forward_64_row_kernel_matches_oracle_and_32_row_kernel(seed, monkeypatch):
+    """attn_fwd2_kernel (two query blocks per wavefront, 32-key tiles; picked automatically from 512 workgroups up) pinned
+    through HVC_ATTN_FWD_ROWS on small ragged shapes: output and log-sum-exp against the oracle, the same dropout mask as the
+    32-row kernel (zero pattern of O for one-hot V), a late spike that forces the deferred rescale, packed strides, and
+    the backward kernels consuming its output."""
+    from hvc import ops
+    from oracle import hvc_oracle as O
+    rng = torch.Generator().manual_seed(14000 + seed)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=rng).item())
+    B, H, D = ri(1, 2), ri(1, 3), (64, 32)[seed % 2]
+    N, M = (ri(1, 700), ri(1, 300)) if seed else (256, 64)
+    qkv = torch.randn(B, max(N, M), 3, H, D, generator=rng)
+    if seed % 3 == 1:
+        qkv[0, M - 1, 1, 0] = qkv[0, min(5, N - 1), 0, 0] * 7.0        # spike in the last key tile
+    qkv = qkv.to(dev(), torch.bfloat16)
+    q, k, v = qkv[:, :N, 0], qkv[:, :M, 1], qkv[:, :M, 2]
+    ref = O.attention_core(*(t.float().cpu().permute(0, 2, 1, 3) for t in (q, k, v)), D ** -0.5).permute(0, 2, 1, 3)
+    rel = lambda a, b: ((a.float().cpu() - b.float().cpu()).abs().max() / max(b.float().abs().max().item(), 1.0)).item()
+    out = {}
+    for rows in ("32", "64"):
+        monkeypatch.setenv("HVC_ATTN_FWD_ROWS", rows)
+        o, lse = ops.attention_fwd(q, k, v, D ** -0.5)
+        assert rel(o, ref) < 3e-2, (rows, B, H, N, M, D)
+        od, lsed = ops.attention_fwd(q, k, v, D ** -0.5, 0.25, 99 + seed)
+        out[rows] = (o, lse, od, lsed)
+    assert rel(out["64"][0], out["32"][0]) < 2e-2
+    assert (out["64"][1] - out["32"][1]).abs().max().item() < 2e-3            # lse (natural log), fp32
+    assert (out["64"][3] - out["32"][3]).abs().max().item() < 2e-3
+    assert rel(out["64"][2], out["32"][2]) < 2e-2                              # same keep mask => same dropped output
+    # the mask itself: V = one-hot over keys in feature 0 .. D-1 (M <= D keys covered), O(q, d) != 0 <=> key d kept
+    if M <= D:
+        eye = torch.zeros(B, M, H, D, device=dev(), dtype=torch.bfloat16)
+        eye[:, torch.arange(M), :, torch.arange(M)] = 1
+        masks = []
+        for rows in ("32", "64"):
+            monkeypatch.setenv("HVC_ATTN_FWD_ROWS", rows)
+            masks.append(ops.attention_fwd(q, k, eye, D ** -0.5, 0.25, 99 + seed)[0] != 0)
+        assert torch.equal(masks[0], masks[1])
+    monkeypatch.setenv("HVC_ATTN_FWD_ROWS", "64")
+    o, lse = out["64"][2], out["64"][3]
+    do = torch.randn(B, N, H, D, generator=rng).to(dev(), torch.bfloat16)
+    _, _, dv = ops.attention_bwd(q, k, v, o, do, lse, D ** -0.5, 0.25, 99 + seed)
+    lhs, rhs = (do.double() * o.double()).sum().item(), (dv.double() * v.double()).sum().item()
+    assert abs(lhs - rhs) < 5e-2 * (abs(lhs) + abs(rhs) + 1.0)
