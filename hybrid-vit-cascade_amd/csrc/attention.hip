@@ -450,15 +450,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const AttnArgs a) {
 
     const int q0 = qb * kQB2 + wave * 64;
     const float sl2 = a.scale * kLog2e;
-    int qrow[2];
-    bool qvalid[2];
     bf16x8 qf[2][1][D / 16];
     uint32_t rowkey[2];
 #pragma unroll
     for (int blk = 0; blk < 2; ++blk) {
-        qrow[blk] = q0 + 32 * blk + r;
-        qvalid[blk] = qrow[blk] < a.Nq;
-        const int qc = qvalid[blk] ? qrow[blk] : a.Nq - 1;
+        const int qc = min(q0 + 32 * blk + r, a.Nq - 1);
         load_row_frags_scaled<T, 1, D / 16, true>(qp + (int64_t)qc * a.q_sn, h, true, sl2, qf[blk]);
         rowkey[blk] = DROP ? drop_rowkey(a, bh, qc) ^ (h ? kGrpH : 0u) : 0u;
     }
@@ -499,7 +495,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const AttnArgs a) {
     commit(0);
     __syncthreads();
 
-    float msc[2] = {0.f, 0.f}, l[2] = {0.f, 0.f};
+    float l[2] = {0.f, 0.f};
     f32x16 negm[2], o[2][D / 32];
 #pragma unroll
     for (int blk = 0; blk < 2; ++blk) {
@@ -526,6 +522,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const AttnArgs a) {
         constexpr bool MASK = decltype(mask_tag)::value;
         constexpr int buf = decltype(buf_tag)::value;            // = t & 1 = which half of the 64-key hash tile
         constexpr int KOFF = (buf * 2 + 0) * TILE, VOFF = (buf * 2 + 1) * TILE;
+        if (t + 1 < nt) issue((t + 1) * kKT2);
         f32x16 st[2] = {negm[0], negm[1]};
 #pragma unroll
         for (int s = 0; s < D / 16; ++s) {
@@ -533,7 +530,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const AttnArgs a) {
 #pragma unroll
             for (int blk = 0; blk < 2; ++blk) st[blk] = mfma32(kf, qf[blk][0][s], st[blk]);
         }
-        if (t + 1 < nt) issue((t + 1) * kKT2);      // after the score chain: the staging registers are idle until the commit
         if constexpr (MASK) {
 #pragma unroll
             for (int blk = 0; blk < 2; ++blk)
@@ -559,12 +555,23 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const AttnArgs a) {
                 for (int dt = 0; dt < D / 32; ++dt)
 #pragma unroll
                     for (int i = 0; i < 16; ++i) o[blk][dt][i] *= alpha;
-                msc[blk] += shift;
+                const float nm = negm[blk][0] - shift;      // the reference exponent lives (negated) in the seed block only
 #pragma unroll
-                for (int i = 0; i < 16; ++i) negm[blk][i] = -msc[blk];
+                for (int i = 0; i < 16; ++i) negm[blk][i] = nm;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) st[blk][i] -= shift;
             }
+        }
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+            float rs = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float p = __builtin_amdgcn_exp2f(st[blk][i]);
+                rs += p;
+                st[blk][i] = p;
+            }
+            l[blk] += rs;
         }
         // O^T[d][q] += V^T P^T: each transposed V fragment serves both query blocks
 #pragma unroll
@@ -574,13 +581,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const AttnArgs a) {
             for (int dt = 0; dt < D / 32; ++dt) vfr[dt] = tr_frag_at(vaddr[dt][0] + (VOFF + 16 * s2 * D), vaddr[dt][1] + (VOFF + 16 * s2 * D));
 #pragma unroll
             for (int blk = 0; blk < 2; ++blk) {
-                float x[8], rs = 0.f;
+                float x[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    x[j] = __builtin_amdgcn_exp2f(st[blk][8 * s2 + j]);
-                    rs += x[j];
-                }
-                l[blk] += rs;
+                for (int j = 0; j < 8; ++j) x[j] = st[blk][8 * s2 + j];
                 bf16x8 pf[1];
                 acc_split<1>(x, pf);
                 if constexpr (DROP) {
@@ -622,8 +625,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const AttnArgs a) {
     for (int blk = 0; blk < 2; ++blk) {
         const float ltot = l[blk] + __shfl_xor(l[blk], 32, 64);
         const float inv = (DROP ? a.keep_scale : 1.f) / ltot;
-        if (qvalid[blk]) {
-            T* orow = op + (int64_t)qrow[blk] * a.o_sn;
+        const int qrow = qb * kQB2 + (int)(threadIdx.x >> 6) * 64 + 32 * blk + (int)(threadIdx.x & 31);      // recomputed: not kept live through the sweep
+        if (qrow < a.Nq) {
+            T* orow = op + (int64_t)qrow * a.o_sn;
 #pragma unroll
             for (int dt = 0; dt < D / 32; ++dt)
 #pragma unroll
@@ -633,7 +637,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const AttnArgs a) {
                     for (int j = 0; j < 4; ++j) w[j] = f2bf(o[blk][dt][4 * g + j] * inv);
                     *reinterpret_cast<bf16x4*>(orow + 32 * dt + 8 * g + 4 * h) = w;
                 }
-            if (h == 0) a.lse[(int64_t)bh * a.Nq + qrow[blk]] = (msc[blk] + __builtin_amdgcn_logf(ltot)) * kLn2;
+            if (h == 0) a.lse[(int64_t)bh * a.Nq + qrow] = (__builtin_amdgcn_logf(ltot) - negm[blk][0]) * kLn2;
         }
     }
 }
