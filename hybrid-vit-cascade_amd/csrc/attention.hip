@@ -970,6 +970,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a) 
         }
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
+            // the next tile's dropout lots are hashed between the two query slices: ahead of the second slice's MFMA chains
+            // rather than in front of the barrier (dK/dV kernel -3 % same-box)
+            if (qt == 1 && t + 1 < nt) gen_lots(t + 1, buf ^ 1);
             // S[q][key] = Q K^T ; dP[q][key] = dO V^T   (key on the lane)
             f32x16 s, dp;
 #pragma unroll
@@ -1049,7 +1052,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a) 
             ql.commit(Qt(buf ^ 1), tid);
             dl.commit(Dt(buf ^ 1), tid);
             commit_stat(buf ^ 1);
-            gen_lots(t + 1, buf ^ 1);
         }
         __syncthreads();
     };
