@@ -770,6 +770,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
             }
         }
         const int kbase = t * kKT;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) st[kt][i] = __builtin_amdgcn_exp2f(st[kt][i]);
         // dS / keep_scale = p * (keep * dP - delta / keep_scale); keep_scale rejoins in the epilogue
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
@@ -780,7 +784,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
                 if constexpr (DROP) drop_keep4((rowkey + (uint32_t)t * kTileAdd) ^ (drop_grp_a(kt) ^ drop_grp_b(i >> 2)), ts, keep);
 #pragma unroll
                 for (int j = 0; j < 4; j += 2) {
-                    f32x2 p2 = {__builtin_amdgcn_exp2f(st[kt][i + j]), __builtin_amdgcn_exp2f(st[kt][i + j + 1])};
+                    f32x2 p2 = {st[kt][i + j], st[kt][i + j + 1]};
                     if constexpr (MASK) {
                         if (key + j >= a.Nk) p2[0] = 0.f;
                         if (key + j + 1 >= a.Nk) p2[1] = 0.f;
@@ -1000,12 +1004,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a) 
             }
             float pd[16], ds[16];
 #pragma unroll
+            for (int i = 0; i < 16; ++i) s[i] = __builtin_amdgcn_exp2f(s[i]);      // all exponentials ahead of the select / multiply pass (-1.3 % same-box)
+#pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int ro = 32 * qt + 8 * g;
 #pragma unroll
                 for (int j = 0; j < 4; j += 2) {
                     const int i = 4 * g + j;
-                    const f32x2 p2 = {__builtin_amdgcn_exp2f(s[i]), __builtin_amdgcn_exp2f(s[i + 1])};
+                    const f32x2 p2 = {s[i], s[i + 1]};
                     f32x2 dp2 = {dp[i], dp[i + 1]};
                     f32x2 pd2 = p2;
                     if constexpr (DROP) {   // 1/(1-p) is folded into delta (pre-divided) and the epilogue scales
