@@ -978,16 +978,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a) 
             // rather than in front of the barrier (dK/dV kernel -3 % same-box)
             if (qt == 1 && t + 1 < nt) gen_lots(t + 1, buf ^ 1);
             // S[q][key] = Q K^T ; dP[q][key] = dO V^T   (key on the lane)
-            f32x16 s, dp;
+            f32x16 s, dp, nd;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {      // accumulator registers 4g .. 4g+3 <-> query rows 32 qt + 8 g + 4 h + {0..3}
                 const int ro = 32 * qt + 8 * g;
                 const f32x4 l4 = *reinterpret_cast<const f32x4*>(stat_lane + ((buf * 2 + 0) * kKT + ro));
                 const f32x4 d4 = *reinterpret_cast<const f32x4*>(stat_lane + ((buf * 2 + 1) * kKT + ro));
+                // dropout: dS = Pd * dP_raw + P * (-delta), so the dP chain starts from zero and -delta is an ordinary operand
+                // (one select per element instead of two, no second copy of the seed block)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { s[4 * g + j] = l4[j]; dp[4 * g + j] = d4[j]; }
+                for (int j = 0; j < 4; ++j) { s[4 * g + j] = l4[j]; nd[4 * g + j] = d4[j]; dp[4 * g + j] = DROP ? 0.f : d4[j]; }
             }
-            const f32x16 nd = dp;              // -delta rows again for the dropped elements
 #pragma unroll
             for (int ks = 0; ks < D / 16; ++ks) {
 #pragma unroll
@@ -1012,8 +1013,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a) 
                 for (int j = 0; j < 4; j += 2) {
                     const int i = 4 * g + j;
                     const f32x2 p2 = {s[i], s[i + 1]};
-                    f32x2 dp2 = {dp[i], dp[i + 1]};
-                    f32x2 pd2 = p2;
+                    const f32x2 dp2 = {dp[i], dp[i + 1]};
+                    f32x2 pd2 = p2, ds2;
                     if constexpr (DROP) {   // 1/(1-p) is folded into delta (pre-divided) and the epilogue scales
 #pragma unroll
                         for (int e = 0; e < 2; ++e) {
@@ -1021,10 +1022,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a) 
                             float pdv = keep ? p2[e] : 0.f;
                             asm("" : "+v"(pdv));     // select in fp32, so that the bf16 conversions below stay packed pairs
                             pd2[e] = pdv;
-                            dp2[e] = keep ? dp2[e] : nd[i + e];
                         }
+                        const f32x2 nd2 = {nd[i], nd[i + 1]};
+                        ds2 = __builtin_elementwise_fma(pd2, dp2, p2 * nd2);      // packed multiply + packed fma
+                    } else {
+                        ds2 = p2 * dp2;                                           // packed multiply
                     }
-                    const f32x2 ds2 = p2 * dp2;      // packed multiply
                     pd[i] = pd2[0]; pd[i + 1] = pd2[1];
                     ds[i] = ds2[0]; ds[i + 1] = ds2[1];
                 }
