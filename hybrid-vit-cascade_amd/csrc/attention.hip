@@ -1223,7 +1223,7 @@ int attention_bwd_qsplit(int B, int H, int Nq, int Nk) {
     const int wgs = ((Nk + kQB - 1) / kQB) * B * H;
     const int nt = (Nq + kKT - 1) / kKT;
     if (wgs >= 512 || nt < 16) return 1;
-    int want = (768 + wgs - 1) / wgs;
+    int want = (512 + wgs - 1) / wgs;          // the kernel runs two workgroups per CU: fill 512 slots in whole rounds (768 left half a round idle)
     if (want > nt / 8) want = nt / 8;          // >= 8 query tiles per slice
     return want < 2 ? 1 : want;
 }
