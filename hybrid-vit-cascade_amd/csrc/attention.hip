@@ -102,8 +102,8 @@ struct TileLoader {
 
 // ---- attention-probability dropout ------------------------------------------------------------------
 // keep(b,h,q,k) = lot16(k & 3 of hash4(rowkey(b,h,q) + (k >> 2) * C)) >= ts.  rowkey is one 32-bit word per
-// query row (computed once per lane, or once per LDS tile row in the dKV kernel); one multiply-xorshift round
-// with two multipliers yields two words of two 16-bit lots each, i.e. four consecutive keys share the hash.
+// query row (computed once per lane, or once per LDS tile row in the dKV kernel); one 64-bit multiply of the mixed word
+// yields two words of two 16-bit lots each (drop_lots4), i.e. four consecutive keys share the hash.
 // Lots are read as SIGNED 16-bit numbers and the threshold is biased accordingly (ts = p * 65536 - 32768):
 //  * forward: a saturating packed subtract + packed arithmetic shift turn a word of two lots into a word of
 //    two 0x0000 / 0xffff keep masks, ANDed onto the packed bf16 probabilities (1.5 instructions / element);
@@ -118,20 +118,29 @@ __device__ __forceinline__ uint32_t drop_rowkey(const AttnArgs& a, int bh, int q
 // for one instruction per group whatever its register layout: in the query-on-lane kernels j & 1 is the lane half,
 // folded into the row key once, and A ^ B is a compile-time constant per group; the dK/dV lot generator keeps
 // both parities of its row key per tile with its thread's A term folded in.
-constexpr uint32_t kLotMulA = 0x7feb352dU, kLotMulB = 0x846ca68bU;
+constexpr uint32_t kLotMulA = 0x7feb352dU;
 constexpr uint32_t kTileAdd = 0x9E3779B9u, kGrpH = 0xB55A4F09u;
 __host__ __device__ constexpr uint32_t drop_grp_a(int j8) { return j8 ? 0xC2B2AE35u : 0x85EBCA6Bu; }
 __host__ __device__ constexpr uint32_t drop_grp_b(int m) { return m == 0 ? 0x27D4EB2Fu : m == 1 ? 0x165667B1u : m == 2 ? 0xD3A2646Cu : 0xFD7046C5u; }
-__device__ __forceinline__ uint32_t drop_lots(uint32_t mixed, uint32_t mul) {        // two 16-bit lots
-    uint32_t y = mixed * mul;
-    return y ^ (y >> 15);
+// Four 16-bit lots from ONE 32 x 32 -> 64-bit multiply (v_mad_u64_u32) instead of two 32-bit multiply-xorshift rounds.
+// The low word is xor-shifted (its low bits see only the low bits of the input) and carries lots 0 / 1.  The high word
+// only spans [0, M) with M = 0x7feb352d ~ 2^31, so lots 2 / 3 are (high + first word): uniform because the first word is,
+// and - the offset being uniform over HALF the range - a drop of lot 2k+1 has probability p / (2 M / 2^32) = 1.0006 p
+// given a drop of the lot above it, i.e. the keep events stay pairwise uncorrelated (the mask statistics test checks the
+// rate and the correlations inside a hash group on the recovered mask).
+__device__ __forceinline__ void drop_lots4(uint32_t mixed, uint32_t& a, uint32_t& b) {
+    const uint64_t pr = (uint64_t)mixed * (uint64_t)kLotMulA;
+    const uint32_t lo = (uint32_t)pr;
+    a = lo ^ (lo >> 15);
+    b = (uint32_t)(pr >> 32) + a;
 }
 __device__ __forceinline__ int drop_ts(const AttnArgs& a) { return (int)a.drop_thresh - 32768; }
 __device__ __forceinline__ bool drop_keep_lo(uint32_t w, int ts) { return (int16_t)w >= (int16_t)ts; }
 __device__ __forceinline__ bool drop_keep_hi(uint32_t w, int ts) { return (int32_t)w >= ts * 65536; }
 // keep flags of the four consecutive keys of one group from its mixed word
 __device__ __forceinline__ void drop_keep4(uint32_t mixed, int ts, bool (&keep)[4]) {
-    const uint32_t a = drop_lots(mixed, kLotMulA), b = drop_lots(mixed, kLotMulB);
+    uint32_t a, b;
+    drop_lots4(mixed, a, b);
     keep[0] = drop_keep_lo(a, ts); keep[1] = drop_keep_hi(a, ts);
     keep[2] = drop_keep_lo(b, ts); keep[3] = drop_keep_hi(b, ts);
 }
@@ -347,8 +356,9 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 3 : 2) void attn_fwd_kernel(c
 #pragma unroll
                     for (int g2 = 0; g2 < 2; ++g2) {      // group j = 8 kt + 2 (2 s2 + g2) + h of tile t
                         const uint32_t m = rk_tile ^ (drop_grp_a(kt) ^ drop_grp_b(2 * s2 + g2));
-                        const uint32_t ma = drop_keepmask2(drop_lots(m, kLotMulA), tm1x2);
-                        const uint32_t mb = drop_keepmask2(drop_lots(m, kLotMulB), tm1x2);
+                        uint32_t la, lb;
+                        drop_lots4(m, la, lb);
+                        const uint32_t ma = drop_keepmask2(la, tm1x2), mb = drop_keepmask2(lb, tm1x2);
 #pragma unroll
                         for (int sa = 0; sa < NS; ++sa) {
                             u32x4 w = __builtin_bit_cast(u32x4, pf[sa]);
@@ -591,8 +601,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const AttnArgs a) {
 #pragma unroll
                     for (int g2 = 0; g2 < 2; ++g2) {      // group j = 8 buf + 2 (2 s2 + g2) + h of hash tile t >> 1
                         const uint32_t m = rk_tile ^ (drop_grp_a(buf) ^ drop_grp_b(2 * s2 + g2));
-                        const uint32_t ma = drop_keepmask2(drop_lots(m, kLotMulA), tm1x2);
-                        const uint32_t mb = drop_keepmask2(drop_lots(m, kLotMulB), tm1x2);
+                        uint32_t la, lb;
+                        drop_lots4(m, la, lb);
+                        const uint32_t ma = drop_keepmask2(la, tm1x2), mb = drop_keepmask2(lb, tm1x2);
                         u32x4 w = __builtin_bit_cast(u32x4, pf[0]);
                         w[2 * g2] &= ma;
                         w[2 * g2 + 1] &= mb;
@@ -924,8 +935,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a) 
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const uint32_t m = rk[u & 1] ^ drop_grp_b(u >> 1);
-                dst[2 * u] = drop_lots(m, kLotMulA);
-                dst[2 * u + 1] = drop_lots(m, kLotMulB);
+                drop_lots4(m, dst[2 * u], dst[2 * u + 1]);
             }
         }
     };

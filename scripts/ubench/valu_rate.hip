@@ -43,6 +43,16 @@ KERNEL(k_lshr, "v_lshrrev_b32 %0, 15, %0\n v_lshrrev_b32 %1, 15, %1\n v_lshrrev_
 KERNEL(k_and_or, "v_and_or_b32 %0, %0, %4, %5\n v_and_or_b32 %1, %1, %4, %5\n v_and_or_b32 %2, %2, %4, %5\n v_and_or_b32 %3, %3, %4, %5")
 KERNEL(k_mul_hi, "v_mul_hi_u32 %0, %0, %4\n v_mul_hi_u32 %1, %1, %4\n v_mul_hi_u32 %2, %2, %4\n v_mul_hi_u32 %3, %3, %4")
 
+// 64-bit multiply-add: one instruction yields four 16-bit lots
+__global__ __launch_bounds__(64) void k_mad_u64(uint32_t* out, int iters, uint32_t b, uint32_t c) {
+    uint64_t a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3;
+    for (int i = 0; i < iters; ++i) {
+        REP8(REP8(asm volatile("v_mad_u64_u32 %0, vcc, %4, %5, %0\n v_mad_u64_u32 %1, vcc, %4, %5, %1\n v_mad_u64_u32 %2, vcc, %4, %5, %2\n v_mad_u64_u32 %3, vcc, %4, %5, %3"
+                               : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b), "v"(c) : "vcc");))
+    }
+    out[blockIdx.x * 64 + threadIdx.x] = (uint32_t)(a0 + a1 + a2 + a3);
+}
+
 template <typename K>
 float run(K k, const char* name, uint32_t* out, float base) {
     hipEvent_t e0, e1;
@@ -65,7 +75,7 @@ int main() {
     hipMalloc(&out, 256 * 4 * 64 * 4);
     float base = run(k_add_f32, "v_add_f32", out, 0);
 #define R(k) run(k, #k, out, base)
-    R(k_fma_f32); R(k_mul_lo); R(k_mul_hi); R(k_mul_u24); R(k_mad_u24); R(k_exp); R(k_cvt_pk); R(k_xor); R(k_xor_sdwa); R(k_bitop3); R(k_perm);
+    R(k_mad_u64); R(k_fma_f32); R(k_mul_lo); R(k_mul_hi); R(k_mul_u24); R(k_mad_u24); R(k_exp); R(k_cvt_pk); R(k_xor); R(k_xor_sdwa); R(k_bitop3); R(k_perm);
     R(k_pk_sub_i16); R(k_pk_ashr_i16); R(k_pk_mul_f32); R(k_pk_add_f32); R(k_pk_fma_f32); R(k_mov_b64); R(k_cmp_cnd); R(k_cmp_sdwa_cnd); R(k_max3); R(k_lshr); R(k_and_or);
     return 0;
 }
