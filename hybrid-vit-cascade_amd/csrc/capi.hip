@@ -434,4 +434,25 @@ int hvc_ssim_l1_bwd(const float* pred, const float* target, const float* gmaps, 
     return hip_result(hvc::ssim_l1_bwd_launch(a, (hipStream_t)stream), "ssim_l1_bwd");
 }
 
+int64_t hvc_tv3d_workspace(int B, int D, int H, int W) {
+    if (B < 1 || D < 1 || H < 1 || W < 1) return -1;
+    return 3 * (int64_t)hvc::loss_blocks((int64_t)B * D * H * W);
+}
+
+int hvc_tv3d_fwd(const float* vol, float* means3, float* workspace, int B, int D, int H, int W, float eps, void* stream) {
+    if (!vol || !means3 || !workspace || B < 1 || D < 1 || H < 1 || W < 1 || !(eps >= 0.f)) return fail(HVC_E_BADARG, "tv3d_fwd: bad operand");
+    hvc::TvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.vol = vol; a.out = means3; a.workspace = workspace; a.B = B; a.D = D; a.H = H; a.W = W; a.eps = eps;
+    return hip_result(hvc::tv3d_fwd_launch(a, (hipStream_t)stream), "tv3d_fwd");
+}
+
+int hvc_tv3d_bwd(const float* vol, const float* gscale, float* dvol, int B, int D, int H, int W, float eps, void* stream) {
+    if (!vol || !gscale || !dvol || B < 1 || D < 1 || H < 1 || W < 1 || !(eps >= 0.f)) return fail(HVC_E_BADARG, "tv3d_bwd: bad operand");
+    hvc::TvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.vol = vol; a.gscale = gscale; a.dvol = dvol; a.B = B; a.D = D; a.H = H; a.W = W; a.eps = eps;
+    return hip_result(hvc::tv3d_bwd_launch(a, (hipStream_t)stream), "tv3d_bwd");
+}
+
 }  // extern "C"

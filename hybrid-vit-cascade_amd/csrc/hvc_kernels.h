@@ -180,4 +180,16 @@ int loss_blocks(int64_t nvox);
 hipError_t ssim_l1_fwd_launch(const LossArgs& a, hipStream_t st);
 hipError_t ssim_l1_bwd_launch(const LossArgs& a, hipStream_t st);
 
+struct TvArgs {
+    const float* vol;        // (B, D, H, W) fp32
+    float* out;              // [3] mean sqrt(diff^2 + eps) along D, H, W
+    float* workspace;        // 3 * loss_blocks(nvox)
+    const float* gscale;     // device [3]: upstream gradients of the three means
+    float* dvol;
+    int B, D, H, W;
+    float eps;
+};
+hipError_t tv3d_fwd_launch(const TvArgs& a, hipStream_t st);
+hipError_t tv3d_bwd_launch(const TvArgs& a, hipStream_t st);
+
 }  // namespace hvc

@@ -135,6 +135,76 @@ int grid_for(int64_t work) {
     return (int)blocks;
 }
 
+
+// ---- total variation (reference: direct_regression/progressive_cascade/loss_multiscale.py:140-188) ----------------------
+// means[a] = mean over the (n_a - 1)-long differences along axis a of sqrt((v[i+1] - v[i])^2 + eps), a = D, H, W; the
+// reference's /3, clamp(0, 100) and the optional |tv_pred - tv_target| act on these three scalars and stay on the host
+// side.  Forward: one pass, every voxel owns its three forward differences; block partials + a fixed-order finish.
+__global__ __launch_bounds__(256) void tv3d_fwd_kernel(const float* __restrict__ v, float* __restrict__ partial, int64_t nvox, int D, int H, int W,
+                                                       float eps) {
+    __shared__ float red[3][4];
+    const int64_t HW = (int64_t)H * W;
+    float acc[3] = {0.f, 0.f, 0.f};
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < nvox; idx += (int64_t)gridDim.x * 256) {
+        const int w = (int)(idx % W), h = (int)((idx / W) % H), d = (int)((idx / HW) % D);
+        const float c = v[idx];
+        if (d + 1 < D) { const float t = v[idx + HW] - c; acc[0] += sqrtf(t * t + eps); }
+        if (h + 1 < H) { const float t = v[idx + W] - c; acc[1] += sqrtf(t * t + eps); }
+        if (w + 1 < W) { const float t = v[idx + 1] - c; acc[2] += sqrtf(t * t + eps); }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float r = wave_sum(acc[a]);
+        if (lane == 0) red[a][wave] = r;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) partial[3 * blockIdx.x + threadIdx.x] = (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
+}
+
+__global__ __launch_bounds__(256) void tv3d_finish_kernel(const float* __restrict__ partial, int nblk, float* out, double inv0, double inv1, double inv2) {
+    __shared__ double red[3][256];
+    double s[3] = {0.0, 0.0, 0.0};
+    for (int i = threadIdx.x; i < nblk; i += 256)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) s[a] += partial[3 * i + a];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) red[a][threadIdx.x] = s[a];
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (threadIdx.x < off)
+#pragma unroll
+            for (int a = 0; a < 3; ++a) red[a][threadIdx.x] += red[a][threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        out[0] = (float)(red[0][0] * inv0);
+        out[1] = (float)(red[1][0] * inv1);
+        out[2] = (float)(red[2][0] * inv2);
+    }
+}
+
+// dv[i] = sum_a gscale[a] / count_a * (g(v[i] - v[i-1]) - g(v[i+1] - v[i])), g(t) = t / sqrt(t^2 + eps): each voxel gathers its
+// (up to) six neighbours - no atomics, one write per voxel.
+__global__ __launch_bounds__(256) void tv3d_bwd_kernel(const float* __restrict__ v, const float* __restrict__ gscale, float* __restrict__ dv, int64_t nvox,
+                                                       int D, int H, int W, float eps, float inv0, float inv1, float inv2) {
+    const int64_t HW = (int64_t)H * W;
+    const float g0 = gscale[0] * inv0, g1 = gscale[1] * inv1, g2 = gscale[2] * inv2;
+    auto g = [eps](float t) { return t * rsqrtf(t * t + eps); };
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < nvox; idx += (int64_t)gridDim.x * 256) {
+        const int w = (int)(idx % W), h = (int)((idx / W) % H), d = (int)((idx / HW) % D);
+        const float c = v[idx];
+        float r = 0.f;
+        if (d > 0) r += g0 * g(c - v[idx - HW]);
+        if (d + 1 < D) r -= g0 * g(v[idx + HW] - c);
+        if (h > 0) r += g1 * g(c - v[idx - W]);
+        if (h + 1 < H) r -= g1 * g(v[idx + W] - c);
+        if (w > 0) r += g2 * g(c - v[idx - 1]);
+        if (w + 1 < W) r -= g2 * g(v[idx + 1] - c);
+        dv[idx] = r;
+    }
+}
+
 }  // namespace
 
 int loss_blocks(int64_t nvox) { return grid_for(nvox); }
@@ -166,6 +236,34 @@ hipError_t ssim_l1_bwd_launch(const LossArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(box_axis_kernel, dim3(grid_for(3 * nvox)), dim3(256), 0, st, A, Bw, 3 * nvox, a.H, (int64_t)a.W, R);
     hipLaunchKernelGGL(ssim_grad_kernel, dim3(grid_for(nvox)), dim3(256), 0, st, Bw, a.pred, a.target, a.gscale, a.dpred, nvox, a.D, HW, R, inv_win,
                        a.l1_w, a.ssim_w);
+    return hipGetLastError();
+}
+
+// workspace: 3 * loss_blocks(nvox) floats.  An axis of extent 1 has no differences: torch's mean over an empty tensor is NaN,
+// and so is ours (0 * inf), as in the reference.
+static void tv_counts(const TvArgs& a, double (&inv)[3]) {
+    const double B = a.B, D = a.D, H = a.H, W = a.W;
+    inv[0] = 1.0 / (B * (D - 1) * H * W);
+    inv[1] = 1.0 / (B * D * (H - 1) * W);
+    inv[2] = 1.0 / (B * D * H * (W - 1));
+}
+
+hipError_t tv3d_fwd_launch(const TvArgs& a, hipStream_t st) {
+    const int64_t nvox = (int64_t)a.B * a.D * a.H * a.W;
+    const int nblk = loss_blocks(nvox);
+    double inv[3];
+    tv_counts(a, inv);
+    hipLaunchKernelGGL(tv3d_fwd_kernel, dim3(nblk), dim3(256), 0, st, a.vol, a.workspace, nvox, a.D, a.H, a.W, a.eps);
+    hipLaunchKernelGGL(tv3d_finish_kernel, dim3(1), dim3(256), 0, st, a.workspace, nblk, a.out, inv[0], inv[1], inv[2]);
+    return hipGetLastError();
+}
+
+hipError_t tv3d_bwd_launch(const TvArgs& a, hipStream_t st) {
+    const int64_t nvox = (int64_t)a.B * a.D * a.H * a.W;
+    double inv[3];
+    tv_counts(a, inv);
+    hipLaunchKernelGGL(tv3d_bwd_kernel, dim3(grid_for(nvox)), dim3(256), 0, st, a.vol, a.gscale, a.dvol, nvox, a.D, a.H, a.W, a.eps, (float)inv[0], (float)inv[1],
+                       (float)inv[2]);
     return hipGetLastError();
 }
 

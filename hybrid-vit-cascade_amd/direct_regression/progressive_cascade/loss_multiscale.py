@@ -1,7 +1,7 @@
 """MI355X-native counterpart of the reference's direct_regression/progressive_cascade/loss_multiscale.py.
 
-HIP: SSIMLoss / L1 (fused box-filter kernel), DRRReprojectionLoss mean projections (ray-sum kernel).
-Plain torch on the GPU ("next"): TotalVariationLoss, FrequencyLoss (rocFFT), bilinear
+HIP: SSIMLoss / L1 (fused box-filter kernel), DRRReprojectionLoss mean projections (ray-sum kernel), TotalVariationLoss
+(one gather pass each way).  Plain torch on the GPU ("next"): FrequencyLoss (rocFFT), bilinear
 resize of the 2-D projections.  TriPlanarVGGLoss needs torchvision's pretrained VGG16 weights, which cannot be
 fetched offline: the term is skipped (reported as 0) unless a `vgg_loss` module is supplied by the caller.
 """
@@ -46,11 +46,12 @@ class TotalVariationLoss(nn.Module):
         self.eps = eps
 
     def _tv(self, v):
-        v = v.float()
-        terms = [torch.sqrt((v[:, :, 1:] - v[:, :, :-1]).pow(2) + self.eps).mean(),
-                 torch.sqrt((v[:, :, :, 1:] - v[:, :, :, :-1]).pow(2) + self.eps).mean(),
-                 torch.sqrt((v[..., 1:] - v[..., :-1]).pow(2) + self.eps).mean()]
-        return torch.clamp(sum(terms) / 3, 0, 100)
+        if not v.is_cuda:
+            raise RuntimeError("TotalVariationLoss runs on the MI355X HIP path only (no CPU fallback)")
+        if v.dim() != 5:
+            raise ValueError("TotalVariationLoss expects (B, C, D, H, W) volumes")
+        means = HF.TotalVariationFn.apply(v, float(self.eps))     # fused HIP pass: the three per-axis means (:162-170)
+        return torch.clamp(means.sum() / 3, 0, 100)
 
     def forward(self, pred_volume, target_volume=None):
         tv = self._tv(pred_volume)

@@ -562,3 +562,21 @@ class SsimL1LossFn(torch.autograd.Function):
         l1_w, ssim_w, window, shape, dtype = ctx.cfg
         dp = ops.ssim_l1_bwd(p, t, gmaps, _f32(dout), window, l1_w, ssim_w).view(shape)
         return (dp if dp.dtype == dtype else dp.to(dtype)), None, None, None, None
+
+
+class TotalVariationFn(torch.autograd.Function):
+    """The three per-axis means of TotalVariationLoss (loss_multiscale.py:162-170) in one pass; backward gathers."""
+
+    @staticmethod
+    def forward(ctx, vol, eps):
+        v = _f32(vol).view(-1, *vol.shape[-3:])            # (B, C, D, H, W): channels are further samples
+        ctx.save_for_backward(v)
+        ctx.cfg = (eps, vol.shape, vol.dtype)
+        return ops.tv3d_fwd(v, eps)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (v,) = ctx.saved_tensors
+        eps, shape, dtype = ctx.cfg
+        dv = ops.tv3d_bwd(v, _f32(dout), eps).view(shape)
+        return (dv if dv.dtype == dtype else dv.to(dtype)), None

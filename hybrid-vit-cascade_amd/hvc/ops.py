@@ -480,3 +480,23 @@ def ssim_l1_bwd(pred, target, gmaps, gscale, window=11, l1_w=1.0, ssim_w=0.5):
     check(_lib.load().hvc_ssim_l1_bwd(pred.data_ptr(), target.data_ptr(), gmaps.data_ptr(), _ptr(_f32c(gscale, "gscale")), dpred.data_ptr(),
                                       ws.data_ptr(), B, D, H, W, int(window), float(l1_w), float(ssim_w), _stream()), "hvc_ssim_l1_bwd")
     return dpred
+
+
+def tv3d_fwd(vol, eps=1e-8):
+    """vol: (B, D, H, W) fp32 contiguous -> means3: mean sqrt(diff^2 + eps) of the forward differences along D, H, W."""
+    _dev(vol)
+    _f32c(vol, "vol")
+    B, D, H, W = vol.shape
+    lib = _lib.load()
+    ws = torch.empty((lib.hvc_tv3d_workspace(B, D, H, W),), dtype=torch.float32, device=vol.device)
+    out = torch.empty((3,), dtype=torch.float32, device=vol.device)
+    check(lib.hvc_tv3d_fwd(vol.data_ptr(), out.data_ptr(), ws.data_ptr(), B, D, H, W, float(eps), _stream()), "hvc_tv3d_fwd")
+    return out
+
+
+def tv3d_bwd(vol, gscale, eps=1e-8):
+    _dev(vol, gscale)
+    B, D, H, W = vol.shape
+    dvol = torch.empty_like(vol)
+    check(_lib.load().hvc_tv3d_bwd(vol.data_ptr(), _ptr(_f32c(gscale, "gscale")), dvol.data_ptr(), B, D, H, W, float(eps), _stream()), "hvc_tv3d_bwd")
+    return dvol

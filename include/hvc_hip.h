@@ -238,6 +238,15 @@ int hvc_ssim_l1_bwd(const float* pred, const float* target, const float* gmaps, 
                     float* dpred, float* workspace, int B, int D, int H, int W, int window, float l1_w,
                     float ssim_w, void* stream);
 
+/* Total variation of (B, 1, D, H, W) fp32 volumes - the per-axis terms of TotalVariationLoss
+ * (reference direct_regression/progressive_cascade/loss_multiscale.py:140-188):
+ * means3[a] = mean sqrt((v[i+1] - v[i])^2 + eps) over the forward differences along a = D, H, W.  The reference's
+ * (sum / 3), clamp(0, 100) and optional |tv_pred - tv_target| are scalar arithmetic on means3 and stay with the caller.
+ * workspace: hvc_tv3d_workspace floats.  bwd: dvol = sum_a gscale[a] * d means3[a] / d vol, gscale a device [3] vector. */
+int64_t hvc_tv3d_workspace(int B, int D, int H, int W);
+int hvc_tv3d_fwd(const float* vol, float* means3, float* workspace, int B, int D, int H, int W, float eps, void* stream);
+int hvc_tv3d_bwd(const float* vol, const float* gscale, float* dvol, int B, int D, int H, int W, float eps, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

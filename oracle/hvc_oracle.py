@@ -289,6 +289,18 @@ def direct_regression_loss(pred, target, l1_weight=1.0, ssim_weight=0.5):
     return {"total_loss": l1_weight * l1 + ssim_weight * ss, "l1_loss": l1, "ssim_loss": ss}
 
 
+def total_variation_loss(pred: torch.Tensor, target: torch.Tensor = None, eps: float = 1e-8) -> torch.Tensor:
+    """TotalVariationLoss.forward, direct_regression/progressive_cascade/loss_multiscale.py:150-188: mean over the three
+    axes of mean sqrt(forward-difference^2 + eps), clamped to [0, 100]; with a target, |tv(pred) - tv(target)|."""
+    def tv(v):
+        v = v.float()
+        terms = [torch.sqrt((v[:, :, 1:] - v[:, :, :-1]).abs().pow(2) + eps).mean(),
+                 torch.sqrt((v[:, :, :, 1:] - v[:, :, :, :-1]).abs().pow(2) + eps).mean(),
+                 torch.sqrt((v[..., 1:] - v[..., :-1]).abs().pow(2) + eps).mean()]
+        return torch.clamp(sum(terms) / 3, 0, 100)
+    return tv(pred) if target is None else F.l1_loss(tv(pred), tv(target))
+
+
 def psnr(pred: torch.Tensor, target: torch.Tensor) -> float:
     """compute_psnr, direct_regression/train_direct_4gpu.py:40-46 (data range 2)."""
     mse = torch.mean((pred - target) ** 2)

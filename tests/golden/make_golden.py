@@ -27,7 +27,7 @@ from models.vit_components import MultiHeadSelfAttention, MultiHeadCrossAttentio
 from models.hybrid_vit_backbone import HybridViTBlock3D, HybridViT3D  # noqa: E402
 from models.diagnostic_losses import XrayConditioningModule, DRRRenderer, ProjectionLoss  # noqa: E402
 from model_direct import DirectCTRegression, DirectRegressionLoss  # noqa: E402
-from loss_multiscale import DRRReprojectionLoss, compute_psnr  # noqa: E402
+from loss_multiscale import DRRReprojectionLoss, TotalVariationLoss, compute_psnr  # noqa: E402
 from model_progressive import MultiScaleXrayEncoder, Stage2Refiner128, Stage3Refiner256  # noqa: E402
 
 OUT = os.path.dirname(os.path.abspath(__file__))
@@ -205,6 +205,22 @@ def drr_fixtures():
                      reproj_ap=rl.generate_drr(vol, 0), reproj_lat=rl.generate_drr(vol, 90)))
 
 
+def tv_fixture():
+    # TotalVariationLoss (loss_multiscale.py:140-188): prediction-only and match-the-target modes, with gradients
+    g = gen(4321)
+    pred = torch.rand(2, 1, 9, 7, 12, generator=g) * 2 - 1
+    target = torch.rand(2, 1, 9, 7, 12, generator=g) * 0.5
+    tv = TotalVariationLoss()
+    p1 = pred.clone().requires_grad_(True)
+    l1 = tv(p1)
+    l1.backward()
+    p2 = pred.clone().requires_grad_(True)
+    l2 = tv(p2, target)
+    l2.backward()
+    flat = torch.full((1, 1, 4, 5, 6), 0.25)                 # all differences zero: sqrt(eps) plateau
+    save("tv", dict(pred=pred, target=target, tv_pred=l1, tv_pred_grad=p1.grad, tv_match=l2, tv_match_grad=p2.grad, tv_flat=tv(flat)))
+
+
 def direct_fixture():
     g = gen(505)
     cfg = dict(volume_size=(16, 16, 16), xray_img_size=64, voxel_dim=32, vit_depth=2, num_heads=1, xray_feature_dim=32)
@@ -287,6 +303,7 @@ if __name__ == "__main__":
     vit3d_fixtures()
     xray_fixtures()
     drr_fixtures()
+    tv_fixture()
     direct_fixture()
     direct_kat()
     cascade_fixture()

@@ -1177,3 +1177,36 @@ def test_attention_forward_64_row_kernel_matches_oracle_and_32_row_kernel(seed, 
     _, _, dv = ops.attention_bwd(q, k, v, o, do, lse, D ** -0.5, 0.25, 99 + seed)
     lhs, rhs = (do.double() * o.double()).sum().item(), (dv.double() * v.double()).sum().item()
     assert abs(lhs - rhs) < 5e-2 * (abs(lhs) + abs(rhs) + 1.0)
+
+
+def test_total_variation_loss_vs_golden_and_oracle(golden):
+    """TotalVariationLoss (loss_multiscale.py:140-188) through the fused HIP pass: the reference's own numbers (both modes,
+    gradients, the sqrt(eps) plateau of a constant volume), then random multi-channel / non-cubic shapes against the oracle,
+    extents of 2 and a bf16 input (cast to fp32 as the reference does)."""
+    from direct_regression.progressive_cascade.loss_multiscale import TotalVariationLoss
+    from oracle import hvc_oracle as O
+    g = golden("tv")
+    tv = TotalVariationLoss()
+    for target, tag in ((None, "tv_pred"), (g.t("target").to(dev()), "tv_match")):
+        p = g.t("pred").to(dev()).requires_grad_(True)
+        loss = tv(p, target)
+        g.check("", tag, loss, 1e-5)
+        loss.backward()
+        g.check("", tag + "_grad", p.grad, 1e-4)
+    g.check("", "tv_flat", tv(torch.full((1, 1, 4, 5, 6), 0.25, device=dev())), 1e-5)
+    gen = torch.Generator().manual_seed(77)
+    for shape, dtype in (((1, 1, 2, 2, 2), torch.float32), ((2, 3, 5, 17, 9), torch.float32), ((1, 1, 33, 20, 64), torch.float32),
+                         ((2, 1, 16, 16, 16), torch.bfloat16)):
+        p = (torch.rand(*shape, generator=gen) * 2 - 1).to(dtype)
+        t = (torch.rand(*shape, generator=gen)).to(dtype)
+        pr = p.clone().requires_grad_(True)
+        ref = O.total_variation_loss(pr, t)
+        ref.backward()
+        pg = p.to(dev()).requires_grad_(True)
+        got = tv(pg, t.to(dev()))
+        got.backward()
+        assert abs(got.item() - ref.item()) < 1e-5 * max(1.0, abs(ref.item())), shape
+        err = (pg.grad.float().cpu() - pr.grad.float()).abs().max() / pr.grad.float().abs().max()
+        assert err < (1e-3 if dtype == torch.float32 else 2e-2), (shape, err.item())
+    with pytest.raises(RuntimeError, match="HIP path only"):
+        tv(torch.zeros(1, 1, 4, 4, 4))

@@ -188,3 +188,14 @@ def test_cascade_refiners_small(golden):
     for pre in ("enc", "s2", "s3"):
         for k in g.keys(f"{pre}_pgrad"):
             g.check(f"{pre}_pgrad", k, P[f"{pre}.{k}"].grad, RTOL, 50)
+
+
+def test_total_variation_loss(golden):
+    g = golden("tv")
+    for target, tag in ((None, "tv_pred"), (g.t("target"), "tv_match")):
+        p = g.t("pred").requires_grad_(True)
+        loss = O.total_variation_loss(p, target)
+        g.check("", tag, loss, RTOL)
+        loss.backward()
+        g.check("", tag + "_grad", p.grad, RTOL)
+    g.check("", "tv_flat", O.total_variation_loss(torch.full((1, 1, 4, 5, 6), 0.25)), RTOL)
