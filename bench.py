@@ -107,7 +107,7 @@ def cpu_baseline(seconds_budget=30.0):
     while True:
         t0 = time.perf_counter()
         opt.zero_grad(set_to_none=True)
-        pred = O.direct_ct_regression(xr, P, training=True, new_stats={})
+        pred = O.direct_ct_regression(xr, P, training=True, new_stats={}, p_drop=0.1)
         loss = O.direct_regression_loss(pred, ct)["total_loss"]
         loss.backward()
         torch.nn.utils.clip_grad_norm_(leaves, 1.0)
@@ -118,8 +118,26 @@ def cpu_baseline(seconds_budget=30.0):
     best = min(times)
     return {"value": 1.0 / best, "unit": "volumes/s", "cores": cores, "kind": "port",
             "sample": f"{len(times)} train step(s) of Direct 64^3, batch 1, fp32 (BASELINE config #1: fwd + L1+0.5*SSIM + bwd + "
-                      f"clip + AdamW) through oracle/hvc_oracle.py on {cores} threads, best step {best:.2f} s; dropout masks "
-                      "omitted (the reference draws them: ~22% of its CPU step)"}
+                      f"clip + AdamW, train mode with the reference's dropout draws p=0.1) through oracle/hvc_oracle.py on "
+                      f"{cores} threads, best step {best:.2f} s"}
+
+
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def spawn_ranks(n):
+    """Run this script as n ranks under torch.distributed.run (one process per GPU); returns the launcher's exit code."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -132,12 +150,16 @@ def main():
     ap.add_argument("--no-profile", action="store_true", help="skip per-kernel HIP-event timing")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # Plain `python bench.py --gpus N`: start the N ranks ourselves (the reference does the same with mp.spawn,
+        # direct_regression/train_direct_4gpu.py:311-339).  The parent has made no GPU call yet and makes none: it
+        # only waits for the torch.distributed.run child and passes on its exit code (rank 0 prints the JSON line).
+        sys.exit(spawn_ranks(args.gpus))
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     if world != args.gpus:
-        if args.gpus != 1 and world == 1:
-            sys.exit(f"--gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...`")
+        sys.exit(f"bench.py: --gpus {args.gpus} disagrees with WORLD_SIZE={world} of the launcher")
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: the HVC hot path has no CPU fallback")
     # HVC_TEST_SINGLE_DEVICE / HVC_DIST_BACKEND exist only to rehearse the N > 1 code path on a one-GPU box
@@ -163,6 +185,9 @@ def main():
         step_model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[device.index], gradient_as_bucket_view=True,
                                                                bucket_cap_mb=32)
     xr, ct = make_batch(wl, rank, device)
+    # identical initial weights on every rank (seed 0 in build(); DDP broadcasts rank 0's anyway), but each
+    # data-parallel replica draws its own dropout seeds, as the reference's per-process generators do
+    torch.manual_seed(1234 + rank)
 
     def barrier():
         if world > 1:
@@ -227,10 +252,12 @@ def main():
             dom = max(agg, key=lambda k: agg[k][0])
             tsec, work, n = agg[dom]
             traffic = None
-            try:   # HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/), same kernel & shape
-                pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-                traffic = pm.get(args.workload, {}).get(dom)
-            except (OSError, ValueError):
+            try:   # HBM bytes per launch from the newest committed rocprofv3 --pmc passes (profiles/), same kernel & shape
+                import glob
+                src = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1]
+                traffic = json.load(open(src)).get(args.workload, {}).get(dom)
+                out["roofline_traffic_source"] = os.path.relpath(src, ROOT)
+            except (OSError, ValueError, IndexError):
                 pass
             out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": work / tsec / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS,
                                "unit": "TFLOP/s", "frac": work / tsec / 1e12 / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic,
@@ -248,6 +275,13 @@ def main():
                                             "launches_per_step": v[2] / share_steps, "avg_launch_ms": 1e3 * v[0] / v[2]}
                                         for k, v in sorted(agg2.items())}
             out["kernel_time_share_note"] = "from an extra untimed pass with every attention / GEMM launch bracketed" if full else "timed region"
+        if world > 1:
+            out["rccl_ranks"] = torch.distributed.get_world_size()
+            out["dist_backend"] = torch.distributed.get_backend()
+            try:
+                out["nccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+            except Exception:       # noqa: BLE001 - informational only
+                out["nccl_version"] = None
         if not args.no_cpu_baseline and world == 1:      # host-CPU baseline: rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

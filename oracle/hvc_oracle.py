@@ -26,43 +26,45 @@ Params = Dict[str, torch.Tensor]
 # attention  (models/vit_components.py)
 # ------------------------------------------------------------------------------------------------
 def attention_core(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float,
-                   q_chunk: Optional[int] = None) -> torch.Tensor:
+                   q_chunk: Optional[int] = None, p_drop: float = 0.0) -> torch.Tensor:
     """softmax(q k^T * scale) v on (B, h, N, d) operands -- models/vit_components.py:46-51 and
-    :103-113 with dropout disabled.  q_chunk bounds the materialised score slab so N = 32768
-    stays tractable on the CPU (identical arithmetic per row)."""
+    :103-113.  p_drop > 0 draws the reference's attn_drop mask on the probabilities (:48, :110; torch's
+    generator, so the masks are torch's, as in the reference's train mode); parity tests use p_drop = 0.
+    q_chunk bounds the materialised score slab so N = 32768 stays tractable on the CPU (identical
+    arithmetic per row)."""
     if q_chunk is None or q.shape[-2] <= q_chunk:
         attn = (q @ k.transpose(-2, -1)) * scale
-        return attn.softmax(dim=-1) @ v
+        return F.dropout(attn.softmax(dim=-1), p_drop, p_drop > 0) @ v
     outs = []
     for s in range(0, q.shape[-2], q_chunk):
         qs = q[..., s:s + q_chunk, :]
-        outs.append(((qs @ k.transpose(-2, -1)) * scale).softmax(dim=-1) @ v)
+        outs.append(F.dropout(((qs @ k.transpose(-2, -1)) * scale).softmax(dim=-1), p_drop, p_drop > 0) @ v)
     return torch.cat(outs, dim=-2)
 
 
 def self_attention(x: torch.Tensor, P: Params, pre: str, num_heads: int,
-                   q_chunk: Optional[int] = None) -> torch.Tensor:
-    """MultiHeadSelfAttention.forward, models/vit_components.py:31-57 (eval / p=0).
-    qkv columns are laid out [q(h,d) | k(h,d) | v(h,d)] (:41-43)."""
+                   q_chunk: Optional[int] = None, p_drop: float = 0.0) -> torch.Tensor:
+    """MultiHeadSelfAttention.forward, models/vit_components.py:31-57 (p_drop = 0: eval; > 0: attn_drop :48
+    and proj_drop :55).  qkv columns are laid out [q(h,d) | k(h,d) | v(h,d)] (:41-43)."""
     B, N, Cn = x.shape
     d = Cn // num_heads
     qkv = F.linear(x, P[pre + "qkv.weight"]).reshape(B, N, 3, num_heads, d).permute(2, 0, 3, 1, 4)
-    o = attention_core(qkv[0], qkv[1], qkv[2], d ** -0.5, q_chunk)
+    o = attention_core(qkv[0], qkv[1], qkv[2], d ** -0.5, q_chunk, p_drop)
     o = o.transpose(1, 2).reshape(B, N, Cn)
-    return F.linear(o, P[pre + "proj.weight"], P[pre + "proj.bias"])
+    return F.dropout(F.linear(o, P[pre + "proj.weight"], P[pre + "proj.bias"]), p_drop, p_drop > 0)
 
 
 def cross_attention(x: torch.Tensor, ctx: torch.Tensor, P: Params, pre: str, num_heads: int,
-                    q_chunk: Optional[int] = None) -> torch.Tensor:
-    """MultiHeadCrossAttention.forward, models/vit_components.py:84-119 (eval / p=0)."""
+                    q_chunk: Optional[int] = None, p_drop: float = 0.0) -> torch.Tensor:
+    """MultiHeadCrossAttention.forward, models/vit_components.py:84-119 (p_drop as in self_attention: :110, :117)."""
     B, N, Cn = x.shape
     M = ctx.shape[1]
     d = Cn // num_heads
     q = F.linear(x, P[pre + "q.weight"]).reshape(B, N, num_heads, d).permute(0, 2, 1, 3)
     kv = F.linear(ctx, P[pre + "kv.weight"]).reshape(B, M, 2, num_heads, d).permute(2, 0, 3, 1, 4)
-    o = attention_core(q, kv[0], kv[1], d ** -0.5, q_chunk)
+    o = attention_core(q, kv[0], kv[1], d ** -0.5, q_chunk, p_drop)
     o = o.transpose(1, 2).reshape(B, N, Cn)
-    return F.linear(o, P[pre + "proj.weight"], P[pre + "proj.bias"])
+    return F.dropout(F.linear(o, P[pre + "proj.weight"], P[pre + "proj.bias"]), p_drop, p_drop > 0)
 
 
 def adaln_params(cond: torch.Tensor, P: Params, pre: str) -> Tuple[torch.Tensor, ...]:
@@ -84,22 +86,23 @@ def sinusoidal_time_embedding(t: torch.Tensor, embed_dim: int) -> torch.Tensor:
 # ViT block / backbone  (models/hybrid_vit_backbone.py)
 # ------------------------------------------------------------------------------------------------
 def vit_block(x: torch.Tensor, ctx: torch.Tensor, cond: torch.Tensor, P: Params, pre: str,
-              num_heads: int, q_chunk: Optional[int] = None) -> torch.Tensor:
+              num_heads: int, q_chunk: Optional[int] = None, p_drop: float = 0.0) -> torch.Tensor:
     """HybridViTBlock3D.forward with use_prev_stage=False, return_attention=False,
-    models/hybrid_vit_backbone.py:88-143."""
+    models/hybrid_vit_backbone.py:88-143 (p_drop > 0: the train-mode nn.Dropout draws of :77, :79 and of the
+    attention modules)."""
     Cn = x.shape[-1]
     shift_sa, scale_sa, gate_sa, shift_mlp, scale_mlp, gate_mlp = adaln_params(cond, P, pre + "adaln.")
     h = F.layer_norm(x, (Cn,), P[pre + "norm1.weight"], P[pre + "norm1.bias"], 1e-5)          # :120
     h = (1 + scale_sa) * h + shift_sa                                                          # :121
-    x = x + gate_sa * self_attention(h, P, pre + "self_attn.", num_heads, q_chunk)             # :122-123
+    x = x + gate_sa * self_attention(h, P, pre + "self_attn.", num_heads, q_chunk, p_drop)     # :122-123
     h = F.layer_norm(x, (Cn,), P[pre + "norm2.weight"], P[pre + "norm2.bias"], 1e-5)          # :126
-    x = x + cross_attention(h, ctx, P, pre + "cross_attn.", num_heads, q_chunk)                # :127-128
+    x = x + cross_attention(h, ctx, P, pre + "cross_attn.", num_heads, q_chunk, p_drop)        # :127-128
     h = F.layer_norm(x, (Cn,), P[pre + "norm3.weight"], P[pre + "norm3.bias"], 1e-5)          # :136
     h = (1 + scale_mlp) * h + shift_mlp                                                        # :137
     h = F.linear(h, P[pre + "mlp.0.weight"], P[pre + "mlp.0.bias"])                            # :75
-    h = F.gelu(h)                                                                              # :76 exact erf
+    h = F.dropout(F.gelu(h), p_drop, p_drop > 0)                                               # :76 exact erf, :77
     h = F.linear(h, P[pre + "mlp.3.weight"], P[pre + "mlp.3.bias"])                            # :78
-    return x + gate_mlp * h                                                                    # :139
+    return x + gate_mlp * F.dropout(h, p_drop, p_drop > 0)                                     # :79, :139
 
 
 def voxel_embed_plan(volume_size: Sequence[int], in_channels: int, voxel_dim: int,
@@ -157,7 +160,7 @@ def voxel_embed(x: torch.Tensor, P: Params, pre: str, layers) -> torch.Tensor:
 def hybrid_vit3d(x: torch.Tensor, ctx: torch.Tensor, cond: torch.Tensor, P: Params, pre: str,
                  volume_size: Sequence[int], in_channels: int, voxel_dim: int, depth: int,
                  num_heads: int, token_grid: Optional[int] = None,
-                 q_chunk: Optional[int] = None) -> torch.Tensor:
+                 q_chunk: Optional[int] = None, p_drop: float = 0.0) -> torch.Tensor:
     """HybridViT3D.forward, models/hybrid_vit_backbone.py:233-274 (token n = (d*H'+h)*W'+w, :255)."""
     layers, _, grid = voxel_embed_plan(volume_size, in_channels, voxel_dim, token_grid)
     B = x.shape[0]
@@ -165,7 +168,7 @@ def hybrid_vit3d(x: torch.Tensor, ctx: torch.Tensor, cond: torch.Tensor, P: Para
     assert tuple(h.shape[2:]) == grid
     h = h.flatten(2).transpose(1, 2) + P[pre + "pos_embed"]                                    # :255-258
     for i in range(depth):
-        h = vit_block(h, ctx, cond, P, f"{pre}blocks.{i}.", num_heads, q_chunk)                # :261-262
+        h = vit_block(h, ctx, cond, P, f"{pre}blocks.{i}.", num_heads, q_chunk, p_drop)        # :261-262
     h = F.layer_norm(h, (voxel_dim,), P[pre + "norm.weight"], P[pre + "norm.bias"], 1e-5)     # :265
     h = F.linear(h, P[pre + "output_proj.weight"], P[pre + "output_proj.bias"])               # :266
     h = h.transpose(1, 2).reshape(B, 1, *grid)                                                 # :269
@@ -259,15 +262,16 @@ def drr_reprojection_loss(pred: torch.Tensor, xrays: torch.Tensor, img_size: int
 def direct_ct_regression(xrays: torch.Tensor, P: Params, volume_size=(64, 64, 64), voxel_dim=256,
                          vit_depth=4, num_heads=4, training: bool = False,
                          new_stats: Optional[Params] = None, token_grid: Optional[int] = None,
-                         q_chunk: Optional[int] = None) -> torch.Tensor:
-    """DirectCTRegression.forward, direct_regression/model_direct.py:59-85."""
+                         q_chunk: Optional[int] = None, p_drop: float = 0.0) -> torch.Tensor:
+    """DirectCTRegression.forward, direct_regression/model_direct.py:59-85 (p_drop = 0.1 with training=True is the
+    reference's train mode: hybrid_vit_backbone.py:38, :166 hard-code dropout 0.1)."""
     B = xrays.shape[0]
     t = torch.zeros(B, 256, dtype=xrays.dtype, device=xrays.device)                            # :69
     _, cond, feats = xray_conditioning(xrays, t, P, "xray_encoder.", training, new_stats)      # :72
     x = P["initial_volume"].expand(B, -1, -1, -1, -1)                                          # :75
     ctx = feats.flatten(2).transpose(1, 2)                                                     # :80
     return hybrid_vit3d(x, ctx, cond, P, "vit_backbone.", volume_size, 1, voxel_dim, vit_depth,
-                        num_heads, token_grid, q_chunk)
+                        num_heads, token_grid, q_chunk, p_drop)
 
 
 def ssim_loss_3d(pred: torch.Tensor, target: torch.Tensor, window: int = 11) -> torch.Tensor:

@@ -154,3 +154,39 @@ def test_progressive_trainer_module_surface():
     assert cfg["training"]["stage2"] == {"num_epochs": 30, "batch_size": 2, "learning_rate": 5e-05, "target_resolution": [128, 128, 128]}
     assert cfg["loss"]["stage3"]["drr"] == 0.3 and cfg["model"]["voxel_dim"] == 256
     assert mod.STAGE_SIZES == {1: (64,) * 3, 2: (128,) * 3, 3: (256,) * 3}
+
+
+def test_bench_rejects_world_size_mismatch_before_touching_the_gpu():
+    """`bench.py --gpus N` inside a launcher whose WORLD_SIZE disagrees must exit non-zero (it used to be
+    accepted silently); the check runs before any GPU call, so it is testable here."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "disagrees with WORLD_SIZE" in (r.stderr + r.stdout)
+
+
+def test_bench_spawn_command_is_a_fresh_torchrun_child(monkeypatch):
+    """Plain `python bench.py --gpus N` starts N ranks as a torch.distributed.run CHILD process (never an exec of the
+    current one) on 127.0.0.1 and hands back its exit code."""
+    import importlib.util
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("hvc_bench", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 7
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3"])
+    assert bench.spawn_ranks(4) == 7
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-4:] == ["--gpus", "4", "--steps", "3"] and cmd[-5].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"

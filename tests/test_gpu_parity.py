@@ -1210,3 +1210,26 @@ def test_total_variation_loss_vs_golden_and_oracle(golden):
         assert err < (1e-3 if dtype == torch.float32 else 2e-2), (shape, err.item())
     with pytest.raises(RuntimeError, match="HIP path only"):
         tv(torch.zeros(1, 1, 4, 4, 4))
+
+
+@pytest.mark.timeout(900)
+def test_bench_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` with no launcher environment starts its own two ranks (torch.distributed.run child) and
+    rank 0 prints one JSON line whose rccl_ranks says two ranks took part.  Rehearsal on the one-GPU test box: both
+    ranks on cuda:0 over gloo (HVC_TEST_SINGLE_DEVICE / HVC_DIST_BACKEND); the production launch is identical with
+    one rank per GPU over nccl = RCCL."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(HVC_TEST_SINGLE_DEVICE="1", HVC_DIST_BACKEND="gloo")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--workload", "direct64", "--no-profile"], env=env, capture_output=True, text=True, timeout=850)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["config"]["global_batch"] == 8
+    assert out["value"] > 0 and out["scaling"] == "weak"
