@@ -455,4 +455,26 @@ int hvc_tv3d_bwd(const float* vol, const float* gscale, float* dvol, int B, int 
     return hip_result(hvc::tv3d_bwd_launch(a, (hipStream_t)stream), "tv3d_bwd");
 }
 
+int64_t hvc_spectral_l1_workspace(int B, int D, int H, int W) {
+    if (B < 1 || D < 1 || H < 1 || W < 1) return -1;
+    return 2 * (int64_t)hvc::loss_blocks((int64_t)B * D * H * W);
+}
+
+int hvc_spectral_l1_fwd(const float* pred_spec, const float* target_spec, float* out2, float* workspace, int B, int D, int H, int W, void* stream) {
+    if (!pred_spec || !target_spec || !out2 || !workspace || B < 1 || D < 1 || H < 1 || W < 1) return fail(HVC_E_BADARG, "spectral_l1_fwd: bad operand");
+    hvc::SpecArgs a;
+    memset(&a, 0, sizeof(a));
+    a.pred = pred_spec; a.target = target_spec; a.out = out2; a.workspace = workspace; a.B = B; a.D = D; a.H = H; a.W = W;
+    return hip_result(hvc::spec_l1_fwd_launch(a, (hipStream_t)stream), "spectral_l1_fwd");
+}
+
+int hvc_spectral_l1_bwd(const float* pred_spec, const float* target_spec, const float* gscale, float* dpred_spec, int B, int D, int H, int W,
+                        void* stream) {
+    if (!pred_spec || !target_spec || !gscale || !dpred_spec || B < 1 || D < 1 || H < 1 || W < 1) return fail(HVC_E_BADARG, "spectral_l1_bwd: bad operand");
+    hvc::SpecArgs a;
+    memset(&a, 0, sizeof(a));
+    a.pred = pred_spec; a.target = target_spec; a.gscale = gscale; a.dpred = dpred_spec; a.B = B; a.D = D; a.H = H; a.W = W;
+    return hip_result(hvc::spec_l1_bwd_launch(a, (hipStream_t)stream), "spectral_l1_bwd");
+}
+
 }  // extern "C"

@@ -192,4 +192,15 @@ struct TvArgs {
 hipError_t tv3d_fwd_launch(const TvArgs& a, hipStream_t st);
 hipError_t tv3d_bwd_launch(const TvArgs& a, hipStream_t st);
 
+struct SpecArgs {
+    const float* pred; const float* target;   // complex spectra, interleaved (re, im): [B][D][H][W][2]
+    float* out;              // [2] (1/N) sum | |P| - |T| | over the low- / high-frequency cells
+    float* workspace;        // 2 * loss_blocks(B*D*H*W)
+    const float* gscale;     // device [2]: upstream gradients of the two terms
+    float* dpred;            // [B][D][H][W][2]
+    int B, D, H, W;
+};
+hipError_t spec_l1_fwd_launch(const SpecArgs& a, hipStream_t st);
+hipError_t spec_l1_bwd_launch(const SpecArgs& a, hipStream_t st);
+
 }  // namespace hvc

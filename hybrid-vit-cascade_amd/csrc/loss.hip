@@ -205,6 +205,62 @@ __global__ __launch_bounds__(256) void tv3d_bwd_kernel(const float* __restrict__
     }
 }
 
+// ---- spectral magnitude L1 (reference: direct_regression/progressive_cascade/loss_multiscale.py:191-236, FrequencyLoss) ----
+// P, T: complex spectra as interleaved (re, im) fp32, [B][D][H][W][2], as the 3-D FFT leaves them (UNSHIFTED).  A cell is
+// "high frequency" when its index lies further than R = min(D,H,W) / 4 from (D/2, H/2, W/2) -- the reference's mask,
+// taken as written (:218-231).  partial[2 blk + {0,1}] = sum over the block's low / high cells of | |P| - |T| |.
+__device__ __forceinline__ bool spec_is_high(int64_t idx, int D, int H, int W, int r2) {
+    const int w = (int)(idx % W), h = (int)((idx / W) % H), d = (int)((idx / ((int64_t)H * W)) % D);
+    const int dd = d - D / 2, dh = h - H / 2, dw = w - W / 2;
+    return dd * dd + dh * dh + dw * dw > r2;       // integers: sqrt(s) > R  <=>  s > R^2
+}
+
+__global__ __launch_bounds__(256) void spec_l1_fwd_kernel(const float2* __restrict__ P, const float2* __restrict__ T, float* __restrict__ partial,
+                                                          int64_t ncell, int D, int H, int W, int r2) {
+    __shared__ float red[2][4];
+    float acc[2] = {0.f, 0.f};
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < ncell; idx += (int64_t)gridDim.x * 256) {
+        const float2 p = P[idx], t = T[idx];
+        const float v = fabsf(sqrtf(p.x * p.x + p.y * p.y) - sqrtf(t.x * t.x + t.y * t.y));
+        acc[spec_is_high(idx, D, H, W, r2) ? 1 : 0] += v;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        const float r = wave_sum(acc[a]);
+        if (lane == 0) red[a][wave] = r;
+    }
+    __syncthreads();
+    if (threadIdx.x < 2) partial[2 * blockIdx.x + threadIdx.x] = (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
+}
+
+__global__ __launch_bounds__(256) void spec_l1_finish_kernel(const float* __restrict__ partial, int nblk, float* out, double inv_n) {
+    __shared__ double red[2][256];
+    double s[2] = {0.0, 0.0};
+    for (int i = threadIdx.x; i < nblk; i += 256) { s[0] += partial[2 * i]; s[1] += partial[2 * i + 1]; }
+    red[0][threadIdx.x] = s[0];
+    red[1][threadIdx.x] = s[1];
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (threadIdx.x < off) { red[0][threadIdx.x] += red[0][threadIdx.x + off]; red[1][threadIdx.x] += red[1][threadIdx.x + off]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { out[0] = (float)(red[0][0] * inv_n); out[1] = (float)(red[1][0] * inv_n); }
+}
+
+// dP = gscale[band] / N * sign(|P| - |T|) * P / |P|  (0 where |P| = 0, as torch.abs' gradient)
+__global__ __launch_bounds__(256) void spec_l1_bwd_kernel(const float2* __restrict__ P, const float2* __restrict__ T, const float* __restrict__ gscale,
+                                                          float2* __restrict__ dP, int64_t ncell, int D, int H, int W, int r2, float inv_n) {
+    const float g[2] = {gscale[0] * inv_n, gscale[1] * inv_n};
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < ncell; idx += (int64_t)gridDim.x * 256) {
+        const float2 p = P[idx], t = T[idx];
+        const float pm = sqrtf(p.x * p.x + p.y * p.y), diff = pm - sqrtf(t.x * t.x + t.y * t.y);
+        const float sgn = diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f);
+        const float c = pm > 0.f ? g[spec_is_high(idx, D, H, W, r2) ? 1 : 0] * sgn / pm : 0.f;
+        dP[idx] = make_float2(c * p.x, c * p.y);
+    }
+}
+
 }  // namespace
 
 int loss_blocks(int64_t nvox) { return grid_for(nvox); }
@@ -264,6 +320,24 @@ hipError_t tv3d_bwd_launch(const TvArgs& a, hipStream_t st) {
     tv_counts(a, inv);
     hipLaunchKernelGGL(tv3d_bwd_kernel, dim3(grid_for(nvox)), dim3(256), 0, st, a.vol, a.gscale, a.dvol, nvox, a.D, a.H, a.W, a.eps, (float)inv[0], (float)inv[1],
                        (float)inv[2]);
+    return hipGetLastError();
+}
+
+// workspace: 2 * loss_blocks(ncell) floats
+hipError_t spec_l1_fwd_launch(const SpecArgs& a, hipStream_t st) {
+    const int64_t ncell = (int64_t)a.B * a.D * a.H * a.W;
+    const int nblk = loss_blocks(ncell);
+    const int R = (a.D < a.H ? (a.D < a.W ? a.D : a.W) : (a.H < a.W ? a.H : a.W)) / 4;
+    hipLaunchKernelGGL(spec_l1_fwd_kernel, dim3(nblk), dim3(256), 0, st, (const float2*)a.pred, (const float2*)a.target, a.workspace, ncell, a.D, a.H, a.W, R * R);
+    hipLaunchKernelGGL(spec_l1_finish_kernel, dim3(1), dim3(256), 0, st, a.workspace, nblk, a.out, 1.0 / (double)ncell);
+    return hipGetLastError();
+}
+
+hipError_t spec_l1_bwd_launch(const SpecArgs& a, hipStream_t st) {
+    const int64_t ncell = (int64_t)a.B * a.D * a.H * a.W;
+    const int R = (a.D < a.H ? (a.D < a.W ? a.D : a.W) : (a.H < a.W ? a.H : a.W)) / 4;
+    hipLaunchKernelGGL(spec_l1_bwd_kernel, dim3(grid_for(ncell)), dim3(256), 0, st, (const float2*)a.pred, (const float2*)a.target, a.gscale, (float2*)a.dpred,
+                       ncell, a.D, a.H, a.W, R * R, (float)(1.0 / (double)ncell));
     return hipGetLastError();
 }
 

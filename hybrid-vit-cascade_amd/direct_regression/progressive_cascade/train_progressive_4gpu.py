@@ -157,10 +157,10 @@ def build_stage(config, stage, checkpoint_dir, device, rank=0):
                 print(f"Loading Stage {stage - 1} checkpoint: {prev}")
             ckpt = torch.load(prev, map_location=device, weights_only=False)
             model.load_state_dict(ckpt["model_state_dict"], strict=False)
+            for prev_stage in range(1, stage):          # frozen only once their weights are loaded (reference :230-232):
+                model.freeze_stage(prev_stage)          # freezing random weights would train the new stage on noise
         elif rank == 0:
             print(f"Warning: Stage {stage - 1} checkpoint not found!")
-        for prev_stage in range(1, stage):
-            model.freeze_stage(prev_stage)
     criterion = MultiScaleLoss(config={k: config["loss"][k] for k in ("stage1", "stage2", "stage3")}).to(device)
     key = f"stage{stage}"
     lr = config["training"][key]["learning_rate"]

@@ -7,7 +7,7 @@ xGMI.  MI355X specifics: autocast runs in bfloat16 (the HIP kernels' MFMA dtype;
 kept as a no-op scale for checkpoint compatibility), gradient buckets are views (no extra copy) sized so the 61 MB
 of gradients go out in two reductions overlapped with the backward pass.
 
-    python train_direct_4gpu.py --config config_direct.json [--resume ckpt.pth] [--synthetic]
+    python train_direct_4gpu.py --config config_direct.json [--resume ckpt.pt] [--synthetic]
     python -m torch.distributed.run --nproc-per-node 8 train_direct_4gpu.py --config ...   (torchrun launch)
 """
 import argparse
@@ -60,10 +60,12 @@ def wrap_ddp(model, device_ids=None, find_unused_parameters=False):
                find_unused_parameters=find_unused_parameters)
 
 
-def train_step(model, criterion, optimizer, scaler, xrays, ct_volume, gradient_clip, autocast_device="cuda"):
-    """One optimisation step (reference train_epoch body, :62-75).  Returns the loss dict."""
+def train_step(model, criterion, optimizer, scaler, xrays, ct_volume, gradient_clip, autocast_device="cuda",
+               autocast_dtype=torch.bfloat16):
+    """One optimisation step (reference train_epoch body, :62-75).  Returns the loss dict.
+    autocast_dtype=None runs the step in fp32 (split-bf16 MFMA products), the mode the parity fixture uses."""
     optimizer.zero_grad(set_to_none=True)
-    with torch.autocast(autocast_device, dtype=torch.bfloat16):
+    with torch.autocast(autocast_device, dtype=autocast_dtype or torch.bfloat16, enabled=autocast_dtype is not None):
         predicted = model(xrays)
         loss_dict = criterion(predicted, ct_volume)
         total_loss = loss_dict["total_loss"]
@@ -120,6 +122,26 @@ def validate(model, dataloader, criterion, rank):
     return {k: v / max(n, 1) for k, v in sums.items()}, psnr / max(n, 1)
 
 
+def save_checkpoint(path, epoch, model, optimizer, scheduler, val_psnr, best_psnr, config):
+    """The reference's checkpoint dict (direct_regression/train_direct_4gpu.py:277-298): unwrapped model state, optimizer,
+    scheduler, epoch, val_psnr, best_psnr, config."""
+    torch.save({"epoch": epoch, "model_state_dict": model.state_dict(), "optimizer_state_dict": optimizer.state_dict(),
+                "scheduler_state_dict": scheduler.state_dict(), "val_psnr": val_psnr, "best_psnr": best_psnr, "config": config}, path)
+
+
+def load_checkpoint(path, model, optimizer, scheduler, map_location):
+    """--resume (reference :177-189).  A missing file is an error, as torch.load makes it in the reference: silently
+    restarting from scratch would later overwrite best_model.  Returns (start_epoch, best_psnr)."""
+    if not os.path.exists(path):
+        raise FileNotFoundError(f"--resume checkpoint not found: {path}")
+    ckpt = torch.load(path, map_location=map_location, weights_only=False)
+    model.load_state_dict(ckpt["model_state_dict"])
+    optimizer.load_state_dict(ckpt["optimizer_state_dict"])
+    if "scheduler_state_dict" in ckpt:
+        scheduler.load_state_dict(ckpt["scheduler_state_dict"])
+    return ckpt["epoch"] + 1, ckpt.get("best_psnr", ckpt.get("val_psnr", 0))
+
+
 def train_ddp(rank, world_size, config, resume_from=None, synthetic=False):
     launched_by_torchrun = "LOCAL_RANK" in os.environ
     if world_size > 1 or launched_by_torchrun:
@@ -138,15 +160,12 @@ def train_ddp(rank, world_size, config, resume_from=None, synthetic=False):
     criterion = DirectRegressionLoss(l1_weight=tr["l1_weight"], ssim_weight=tr["ssim_weight"])
 
     start_epoch, best_psnr = 1, 0.0
-    if resume_from and os.path.exists(resume_from):
-        ckpt = torch.load(resume_from, map_location=f"cuda:{rank}", weights_only=False)
-        model.load_state_dict(ckpt["model_state_dict"])
-        optimizer.load_state_dict(ckpt["optimizer_state_dict"])
-        if "scheduler_state_dict" in ckpt:
-            scheduler.load_state_dict(ckpt["scheduler_state_dict"])
-        start_epoch, best_psnr = ckpt["epoch"] + 1, ckpt.get("best_psnr", 0.0)
+    if resume_from is not None:
         if rank == 0:
-            print(f"\nResuming from epoch {ckpt['epoch']}\nBest PSNR so far: {best_psnr:.2f} dB")
+            print(f"\nResuming from checkpoint: {resume_from}")
+        start_epoch, best_psnr = load_checkpoint(resume_from, model, optimizer, scheduler, f"cuda:{rank}")
+        if rank == 0:
+            print(f"Resuming from epoch {start_epoch - 1}\nBest PSNR so far: {best_psnr:.2f} dB")
 
     data = config["data"]
     full = PatientDRRDataset(data_path=None if synthetic else data["dataset_path"], target_xray_size=config["model"]["xray_img_size"],
@@ -156,7 +175,7 @@ def train_ddp(rank, world_size, config, resume_from=None, synthetic=False):
     train_sampler = DistributedSampler(train_ds, num_replicas=world_size, rank=rank, shuffle=True) if dist.is_initialized() else None
     val_sampler = DistributedSampler(val_ds, num_replicas=world_size, rank=rank, shuffle=False) if dist.is_initialized() else None
     train_loader = DataLoader(train_ds, batch_size=tr["batch_size"], sampler=train_sampler, shuffle=train_sampler is None,
-                              num_workers=data["num_workers"], pin_memory=True, drop_last=True)
+                              num_workers=data["num_workers"], pin_memory=True)
     val_loader = DataLoader(val_ds, batch_size=tr["batch_size"], sampler=val_sampler, shuffle=False,
                             num_workers=data["num_workers"], pin_memory=True)
     save_dir = config["checkpoints"]["save_dir"]
@@ -174,15 +193,13 @@ def train_ddp(rank, world_size, config, resume_from=None, synthetic=False):
             print(f"\nEpoch {epoch} Training Summary:\n  Total Loss: {losses['total']:.4f}\n  L1 Loss: {losses['l1']:.4f}\n"
                   f"  SSIM Loss: {losses['ssim']:.4f}\n\nValidation Results:\n  Total Loss: {val_losses['total']:.4f}\n"
                   f"  L1 Loss: {val_losses['l1']:.4f}\n  SSIM Loss: {val_losses['ssim']:.4f}\n  PSNR: {val_psnr:.2f} dB")
-            state = {"epoch": epoch, "model_state_dict": model.state_dict(), "optimizer_state_dict": optimizer.state_dict(),
-                     "scheduler_state_dict": scheduler.state_dict(), "val_psnr": val_psnr, "best_psnr": max(best_psnr, val_psnr),
-                     "config": config}
-            if val_psnr > best_psnr:
+            if val_psnr > best_psnr:                     # file names as the reference writes them (:277, :290)
                 best_psnr = val_psnr
-                torch.save(state, os.path.join(save_dir, "best_model.pth"))
+                save_checkpoint(os.path.join(save_dir, "best_model.pt"), epoch, model, optimizer, scheduler, val_psnr, best_psnr, config)
                 print(f"  ✓ New best model saved! PSNR: {best_psnr:.2f} dB")
             if epoch % config["checkpoints"]["save_every"] == 0:
-                torch.save(state, os.path.join(save_dir, f"checkpoint_epoch_{epoch}.pth"))
+                save_checkpoint(os.path.join(save_dir, f"checkpoint_epoch_{epoch}.pt"), epoch, model, optimizer, scheduler, val_psnr,
+                                best_psnr, config)
                 print(f"  ✓ Periodic checkpoint saved at epoch {epoch}")
         scheduler.step()
     if rank == 0:

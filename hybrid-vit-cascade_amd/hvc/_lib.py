@@ -51,6 +51,9 @@ SIGNATURES = {
     "hvc_tv3d_workspace": (_i64, [_i, _i, _i, _i]),
     "hvc_tv3d_fwd": (_i, [_p] * 3 + [_i] * 4 + [_f, _p]),
     "hvc_tv3d_bwd": (_i, [_p] * 3 + [_i] * 4 + [_f, _p]),
+    "hvc_spectral_l1_workspace": (_i64, [_i, _i, _i, _i]),
+    "hvc_spectral_l1_fwd": (_i, [_p] * 4 + [_i] * 4 + [_p]),
+    "hvc_spectral_l1_bwd": (_i, [_p] * 4 + [_i] * 4 + [_p]),
     "hvc_drr_fwd": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _f, _f, _f, _i, _i, _p]),
     "hvc_drr_bwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _f, _f, _i, _i, _p]),
 }

@@ -28,16 +28,23 @@ def compute_dtype(ref: torch.Tensor) -> torch.dtype:
     return torch.float32
 
 
-# ---- weight casts are cached ON the parameter object, keyed by its version counter: parameters
-# change once per optimizer step, so the bf16 copies are refreshed once per step, not per use.
+# ---- weight casts are cached ON the parameter object, keyed by its version counter, device and storage address:
+# parameters change once per optimizer step, so the bf16 copies are refreshed once per step, not per use.  The key
+# covers optimizer steps, load_state_dict, `p.data = ...` and module.to(device) (new storage).  The one write it cannot
+# see is an IN-PLACE write through `.data` (p.data.mul_(..), EMA updates): same storage, and `.data` has its own version
+# counter -- call invalidate_param_casts() after such a write.
 _CAST_EPOCH = 0
 
 
 def invalidate_param_casts():
-    """Drop every cached low-precision weight copy (call after writing parameters through `.data`,
+    """Drop every cached low-precision weight copy (call after writing parameters in place through `.data`,
     which does not bump the tensor version counter)."""
     global _CAST_EPOCH
     _CAST_EPOCH += 1
+
+
+def _cache_key(p, *extra):
+    return (p._version, _CAST_EPOCH, p.device, p.data_ptr(), *extra)
 
 
 def cast_param(p: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
@@ -45,12 +52,12 @@ def cast_param(p: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
         d = p.detach()
         return d if d.is_contiguous() else d.contiguous()
     hit = getattr(p, "_hvc_cast", None)
-    ver = p._version
-    if hit is not None and hit[0] == (ver, _CAST_EPOCH, dtype):
+    key = _cache_key(p, dtype)
+    if hit is not None and hit[0] == key:
         return hit[1]
     out = ops.cast(p.detach(), dtype)
     try:
-        p._hvc_cast = ((ver, _CAST_EPOCH, dtype), out)
+        p._hvc_cast = (key, out)
     except AttributeError:
         pass
     return out
@@ -352,7 +359,7 @@ def drr_project(vol, axis, *, exp_mode, mu=0.3, out_scale=1.0, clamp_min=float("
 # --------------------------------------------------------------------------------------------
 def conv_weight_2d(weight: torch.Tensor, dtype: torch.dtype, Kp: int) -> torch.Tensor:
     """(Cout, Cin, *k) parameter -> GEMM operand (Cout, Kp), column = tap * Cin + c; cached per version."""
-    key = (weight._version, _CAST_EPOCH, dtype, Kp)
+    key = _cache_key(weight, dtype, Kp)
     hit = getattr(weight, "_hvc_w2d", None)
     if hit is not None and hit[0] == key:
         return hit[1]
@@ -580,3 +587,19 @@ class TotalVariationFn(torch.autograd.Function):
         eps, shape, dtype = ctx.cfg
         dv = ops.tv3d_bwd(v, _f32(dout), eps).view(shape)
         return (dv if dv.dtype == dtype else dv.to(dtype)), None
+
+
+class SpectralL1Fn(torch.autograd.Function):
+    """(low, high) magnitude-spectrum L1 terms of FrequencyLoss (loss_multiscale.py:203-236) from the (B,D,H,W,2) real views
+    of the two spectra; the gradient flows to the prediction's spectrum only (the target carries none in the trainers)."""
+
+    @staticmethod
+    def forward(ctx, pred_spec, target_spec):
+        p, t = pred_spec.detach().contiguous(), target_spec.detach().contiguous()
+        ctx.save_for_backward(p, t)
+        return ops.spectral_l1_fwd(p, t)
+
+    @staticmethod
+    def backward(ctx, dout):
+        p, t = ctx.saved_tensors
+        return ops.spectral_l1_bwd(p, t, _f32(dout)), None

@@ -500,3 +500,27 @@ def tv3d_bwd(vol, gscale, eps=1e-8):
     dvol = torch.empty_like(vol)
     check(_lib.load().hvc_tv3d_bwd(vol.data_ptr(), _ptr(_f32c(gscale, "gscale")), dvol.data_ptr(), B, D, H, W, float(eps), _stream()), "hvc_tv3d_bwd")
     return dvol
+
+
+def spectral_l1_fwd(pred_spec, target_spec):
+    """pred_spec / target_spec: (B, D, H, W, 2) fp32 contiguous (torch.view_as_real of the 3-D FFTs) -> out2 (low, high)."""
+    _dev(pred_spec, target_spec)
+    _f32c(pred_spec, "pred_spec"), _f32c(target_spec, "target_spec")
+    if pred_spec.dim() != 5 or pred_spec.shape[-1] != 2 or pred_spec.shape != target_spec.shape:
+        raise ValueError("spectral_l1: (B, D, H, W, 2) spectra of equal shape expected")
+    B, D, H, W, _ = pred_spec.shape
+    lib = _lib.load()
+    ws = torch.empty((lib.hvc_spectral_l1_workspace(B, D, H, W),), dtype=torch.float32, device=pred_spec.device)
+    out = torch.empty((2,), dtype=torch.float32, device=pred_spec.device)
+    check(lib.hvc_spectral_l1_fwd(pred_spec.data_ptr(), target_spec.data_ptr(), out.data_ptr(), ws.data_ptr(), B, D, H, W, _stream()),
+          "hvc_spectral_l1_fwd")
+    return out
+
+
+def spectral_l1_bwd(pred_spec, target_spec, gscale):
+    _dev(pred_spec, target_spec, gscale)
+    B, D, H, W, _ = pred_spec.shape
+    d = torch.empty_like(pred_spec)
+    check(_lib.load().hvc_spectral_l1_bwd(pred_spec.data_ptr(), target_spec.data_ptr(), _ptr(_f32c(gscale, "gscale")), d.data_ptr(),
+                                          B, D, H, W, _stream()), "hvc_spectral_l1_bwd")
+    return d

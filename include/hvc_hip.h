@@ -247,6 +247,19 @@ int64_t hvc_tv3d_workspace(int B, int D, int H, int W);
 int hvc_tv3d_fwd(const float* vol, float* means3, float* workspace, int B, int D, int H, int W, float eps, void* stream);
 int hvc_tv3d_bwd(const float* vol, const float* gscale, float* dvol, int B, int D, int H, int W, float eps, void* stream);
 
+/* Magnitude-spectrum L1 terms of FrequencyLoss (reference direct_regression/progressive_cascade/loss_multiscale.py:191-236).
+ * pred_spec / target_spec: the 3-D FFTs (over D, H, W; UNSHIFTED, as torch.fft.fftn / rocFFT leave them) of the two volumes as
+ * interleaved (re, im) fp32, [B][D][H][W][2].  A cell is "high frequency" when its index is further than min(D,H,W)/4 from
+ * (D/2, H/2, W/2) -- the reference's mask as written (:218-231).  out2 = (1/N) sum | |P| - |T| | over the low / the high cells,
+ * N = B*D*H*W; the reference's  low + high_freq_weight * high  is scalar arithmetic and stays with the caller.
+ * bwd: dpred_spec = sum_i gscale[i] * d out2[i] / d pred_spec (as a real pair per cell), gscale a device [2] vector.
+ * workspace: hvc_spectral_l1_workspace floats.  The transform itself is the vendor FFT (rocFFT), called by the host side. */
+int64_t hvc_spectral_l1_workspace(int B, int D, int H, int W);
+int hvc_spectral_l1_fwd(const float* pred_spec, const float* target_spec, float* out2, float* workspace, int B, int D, int H, int W,
+                        void* stream);
+int hvc_spectral_l1_bwd(const float* pred_spec, const float* target_spec, const float* gscale, float* dpred_spec,
+                        int B, int D, int H, int W, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

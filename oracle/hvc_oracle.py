@@ -191,30 +191,56 @@ def _bn(x, P, pre, training, new_stats):
     return F.batch_norm(x, rm, rv, P[pre + "weight"], P[pre + "bias"], False, 0.1, 1e-5)
 
 
+def _relu_pool(b: torch.Tensor, pool, tag: str, route: Optional[dict]) -> torch.Tensor:
+    """ReLU (+ MaxPool2d(k, s, p)) with the ROUTING made explicit.  route = None: plain F.relu / F.max_pool2d.
+    Otherwise route["own"][tag] records this evaluation's routing -- relu mask (b > 0) and, per pooled window, the
+    flat h*W+w index of its arg-max -- and, when route["use"] holds an entry for tag, the output is formed with THAT
+    routing instead (mask multiply + gather): the same function wherever the two routings agree, and a smooth function
+    of its inputs for a fixed routing, which is what a gradient comparison across implementations needs (a near-tie
+    that rounds the other way re-routes a whole window's gradient)."""
+    if route is None:
+        r = F.relu(b)
+        return r if pool is None else F.max_pool2d(r, *pool)
+    own = route.setdefault("own", {})
+    mask = b > 0
+    rec = {"relu": mask}
+    r = F.relu(b)
+    if pool is not None:
+        pooled, idx = F.max_pool2d(r, *pool, return_indices=True)
+        rec["argmax"], rec["max"] = idx, pooled.detach()
+    own[tag] = rec
+    use = route.get("use", {}).get(tag)
+    if use is None:
+        return r if pool is None else pooled
+    r = b * use["relu"].to(b.dtype)
+    if pool is None:
+        return r
+    idx = use["argmax"]
+    return r.flatten(2).gather(2, idx.flatten(2)).view(idx.shape)
+
+
 def xray_encoder(x: torch.Tensor, P: Params, pre: str, training: bool = False,
-                 new_stats: Optional[Params] = None) -> torch.Tensor:
+                 new_stats: Optional[Params] = None, route: Optional[dict] = None) -> torch.Tensor:
     """self.encoder, models/diagnostic_losses.py:82-96: Conv7x7 s2 p3 -> BN -> ReLU -> MaxPool(3,2,1)
-    -> Conv3x3 p1 -> BN -> ReLU -> MaxPool(2,2) -> Conv3x3 p1 -> BN -> ReLU."""
+    -> Conv3x3 p1 -> BN -> ReLU -> MaxPool(2,2) -> Conv3x3 p1 -> BN -> ReLU.  route: see _relu_pool."""
     x = F.conv2d(x, P[pre + "0.weight"], P[pre + "0.bias"], stride=2, padding=3)
-    x = F.relu(_bn(x, P, pre + "1.", training, new_stats))
-    x = F.max_pool2d(x, 3, 2, 1)
+    x = _relu_pool(_bn(x, P, pre + "1.", training, new_stats), (3, 2, 1), "1", route)
     x = F.conv2d(x, P[pre + "4.weight"], P[pre + "4.bias"], padding=1)
-    x = F.relu(_bn(x, P, pre + "5.", training, new_stats))
-    x = F.max_pool2d(x, 2, 2)
+    x = _relu_pool(_bn(x, P, pre + "5.", training, new_stats), (2, 2, 0), "5", route)
     x = F.conv2d(x, P[pre + "8.weight"], P[pre + "8.bias"], padding=1)
-    return F.relu(_bn(x, P, pre + "9.", training, new_stats))
+    return _relu_pool(_bn(x, P, pre + "9.", training, new_stats), None, "9", route)
 
 
 def xray_conditioning(xrays: torch.Tensor, t: torch.Tensor, P: Params, pre: str,
-                      training: bool = False, new_stats: Optional[Params] = None):
+                      training: bool = False, new_stats: Optional[Params] = None, route: Optional[dict] = None):
     """XrayConditioningModule.forward, models/diagnostic_losses.py:108-138.
     Returns (xray_context (B,cond), time_xray_cond (B,cond), features (B,E,H',W'))."""
     B, V = xrays.shape[0], xrays.shape[1]
     if V > 1:
-        f = xray_encoder(xrays.reshape(B * V, *xrays.shape[2:]), P, pre + "encoder.", training, new_stats)  # :123-124
+        f = xray_encoder(xrays.reshape(B * V, *xrays.shape[2:]), P, pre + "encoder.", training, new_stats, route)  # :123-124
         f = f.view(B, V, *f.shape[1:]).mean(dim=1)                                                          # :126
     else:
-        f = xray_encoder(xrays[:, 0], P, pre + "encoder.", training, new_stats)                             # :128
+        f = xray_encoder(xrays[:, 0], P, pre + "encoder.", training, new_stats, route)                      # :128
     xc = F.linear(f.mean(dim=[-2, -1]), P[pre + "to_cond.weight"], P[pre + "to_cond.bias"])                # :131-132
     te = F.linear(t, P[pre + "time_mlp.0.weight"], P[pre + "time_mlp.0.bias"])                             # :99-103
     te = F.linear(F.silu(te), P[pre + "time_mlp.2.weight"], P[pre + "time_mlp.2.bias"])

@@ -89,6 +89,31 @@ class Golden:
         return err
 
 
+    def ref_values(self, prefix, name, like=None):
+        """Stored reference values as a flat float64 array: the whole tensor, or its probes for compacted entries.
+        Returns (ref, picker) where picker(flat_tensor) selects the matching elements of a same-shaped tensor."""
+        key = f"{prefix}/{name}" if prefix else name
+        if key in self.z.files:
+            return self.z[key].astype(np.float64).reshape(-1), (lambda v: v.reshape(-1))
+        ref = self.z[key + "#probe"].astype(np.float64)
+        idx = probe_indices(int(self.z[key + "#stats"][2]))
+        return ref, (lambda v: v.reshape(-1)[idx])
+
+    def check_step_move(self, before_prefix, after_prefix, name, before, after, lr, frac_tol, move_tol=0.05):
+        """Optimizer-step comparison on the MOVE of a parameter (after - before), in units of the learning rate: AdamW
+        moves every weight by <= ~lr whatever the gradient's size, so weights are compared by how far they moved.
+        At most `frac_tol` of the elements may differ by more than move_tol * lr (elements whose gradient is ~0 move
+        by a sign-like +-lr on the first step, so rounding may flip them); returns that fraction."""
+        ref_after, pick = self.ref_values(after_prefix, name)
+        ref_before = self.z[f"{before_prefix}/{name}"].astype(np.float64)
+        ref_move = ref_after - pick(ref_before)
+        got_move = pick((after.detach().double() - before.detach().double()).cpu().numpy())
+        bad = np.abs(got_move - ref_move) > move_tol * lr
+        frac = float(bad.mean())
+        assert frac <= frac_tol, f"{after_prefix}/{name}: {frac:.2%} of the weights moved differently (> {move_tol} lr)"
+        return frac
+
+
 @pytest.fixture(scope="session")
 def golden():
     cache = {}

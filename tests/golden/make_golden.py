@@ -23,11 +23,11 @@ sys.path.insert(0, REF)
 sys.path.insert(0, os.path.join(REF, "direct_regression"))
 sys.path.insert(0, os.path.join(REF, "direct_regression", "progressive_cascade"))
 
-from models.vit_components import MultiHeadSelfAttention, MultiHeadCrossAttention, AdaLNModulation  # noqa: E402
+from models.vit_components import MultiHeadSelfAttention, MultiHeadCrossAttention, AdaLNModulation, SinusoidalTimeEmbedding  # noqa: E402
 from models.hybrid_vit_backbone import HybridViTBlock3D, HybridViT3D  # noqa: E402
 from models.diagnostic_losses import XrayConditioningModule, DRRRenderer, ProjectionLoss  # noqa: E402
 from model_direct import DirectCTRegression, DirectRegressionLoss  # noqa: E402
-from loss_multiscale import DRRReprojectionLoss, TotalVariationLoss, compute_psnr  # noqa: E402
+from loss_multiscale import DRRReprojectionLoss, TotalVariationLoss, FrequencyLoss, compute_psnr  # noqa: E402
 from model_progressive import MultiScaleXrayEncoder, Stage2Refiner128, Stage3Refiner256  # noqa: E402
 
 OUT = os.path.dirname(os.path.abspath(__file__))
@@ -282,6 +282,60 @@ def cascade_fixture():
                                s3_pgrad={k: p.grad.clone() for k, p in s3.named_parameters() if p.grad is not None}))
 
 
+def time_embedding_fixture():
+    # SinusoidalTimeEmbedding (models/vit_components.py:152-174): integer-like and fractional timesteps, two widths
+    g = gen(707)
+    t = torch.cat([torch.tensor([0.0, 1.0, 17.0, 999.0]), torch.rand(4, generator=g) * 1000])
+    save("time_embedding", dict(t=t, emb32=SinusoidalTimeEmbedding(32)(t), emb256=SinusoidalTimeEmbedding(256)(t)))
+
+
+def frequency_fixture():
+    # FrequencyLoss (loss_multiscale.py:191-236) on a non-cubic volume (the mask is centred on D//2, H//2, W//2 of the
+    # UNSHIFTED spectrum, radius min(D,H,W)//4), loss and gradient, default and custom high-frequency weight
+    g = gen(808)
+    pred = torch.rand(2, 1, 12, 10, 16, generator=g) * 2 - 1
+    target = torch.rand(2, 1, 12, 10, 16, generator=g) * 2 - 1
+    arrays = dict(pred=pred, target=target)
+    for tag, w in (("w2", 2.0), ("w05", 0.5)):
+        p = pred.clone().requires_grad_(True)
+        loss = FrequencyLoss(high_freq_weight=w)(p, target)
+        loss.backward()
+        arrays[f"loss_{tag}"], arrays[f"grad_{tag}"] = loss, p.grad
+    save("frequency", arrays)
+
+
+def train_step_fixture():
+    """One optimisation step of the reference's direct trainer (direct_regression/train_direct_4gpu.py:59-75; the script
+    itself cannot be imported here - nibabel - so its loop body is restated on the imported reference model):
+    zero_grad -> forward -> DirectRegressionLoss(1.0, 0.5) -> backward -> clip_grad_norm_(1.0) -> AdamW(1e-4, wd 0.01).step(),
+    train mode (BatchNorm batch statistics), dropout p = 0 (masks are not reproducible), fp32 on the CPU (autocast and
+    GradScaler are no-ops there, train_direct.py:51,174).  Two consecutive steps, so the second one sees Adam state."""
+    g = gen(909)
+    cfg = dict(volume_size=(16, 16, 16), xray_img_size=64, voxel_dim=32, vit_depth=2, num_heads=1, xray_feature_dim=32)
+    torch.manual_seed(19)
+    m = DirectCTRegression(**cfg)
+    reinit_adaln(m, g)
+    zero_dropout(m)
+    m.train()
+    xr = randn(g, 2, 2, 1, 64, 64)
+    target = torch.rand(2, 1, 16, 16, 16, generator=g) * 2 - 1
+    crit = DirectRegressionLoss(1.0, 0.5)
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-4, weight_decay=0.01)
+    arrays = dict(cfg=np.array([16, 16, 16, 64, 32, 2, 1, 32]), xrays=xr, target=target,
+                  params={k: v.clone() for k, v in m.state_dict().items()})
+    for step in (1, 2):
+        opt.zero_grad()
+        pred = m(xr)
+        loss = crit(pred, target)["total_loss"]
+        loss.backward()
+        norm = torch.nn.utils.clip_grad_norm_(m.parameters(), 1.0)
+        arrays[f"step{step}_loss"], arrays[f"step{step}_gradnorm"] = loss.detach(), norm
+        arrays[f"step{step}_clipped"] = {k: p.grad.clone() for k, p in m.named_parameters()}
+        opt.step()
+        arrays[f"step{step}_after"] = {k: v.clone() for k, v in m.state_dict().items()}
+    save("train_step", arrays, compact=("clipped", "after"))
+
+
 def direct_kat():
     """Full-size known answers: values only, no tensors."""
     torch.manual_seed(0)
@@ -307,3 +361,6 @@ if __name__ == "__main__":
     direct_fixture()
     direct_kat()
     cascade_fixture()
+    time_embedding_fixture()
+    frequency_fixture()
+    train_step_fixture()

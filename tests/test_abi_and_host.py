@@ -190,3 +190,122 @@ def test_bench_spawn_command_is_a_fresh_torchrun_child(monkeypatch):
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
     assert cmd[-4:] == ["--gpus", "4", "--steps", "3"] and cmd[-5].endswith("bench.py")
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def _write_patient(root, pid, rng, ct_shape=(6, 5, 4), frontal_name=None, lateral_name=None, ct_ext=".npy"):
+    import numpy as np
+    d = root / pid
+    d.mkdir()
+    ct = rng.uniform(-1000, 1500, size=ct_shape).astype(np.float32)              # Hounsfield units, beyond the window both ways
+    frontal = rng.uniform(0, 255, size=(8, 8)).astype(np.float32)                # 8-bit grey levels
+    lateral = rng.uniform(0, 1, size=(8, 8)).astype(np.float32) * 0.9            # already in [0, 1]
+    np.save(d / (frontal_name or f"{pid}_pa_drr.npy"), frontal)
+    np.save(d / (lateral_name or f"{pid}_lat_drr.npy"), lateral)
+    np.save(d / f"{pid}{ct_ext}", ct)
+    return ct, frontal, lateral
+
+
+def test_real_data_loader_follows_the_reference_contract(tmp_path):
+    """utils/dataset.py of the reference (:98-229, :285-349) on a fake patient tree of .npy files: view order (frontal / PA
+    is view 0 although `*_lat_*` sorts first), the CT file is `pid.npy` and is not mistaken for a view, HU window
+    [-200, 200] -> [-1, 1], DRRs / 255 only when they exceed 1, resize modes, vertical flip, item keys."""
+    import numpy as np
+    import torch.nn.functional as F
+    from utils.dataset import PatientDRRDataset
+    rng = np.random.default_rng(7)
+    ct, frontal, lateral = _write_patient(tmp_path, "p001", rng)
+    _write_patient(tmp_path, "p002", rng, frontal_name="p002_frontal.npy", lateral_name="p002_lateral.npy")
+    (tmp_path / "p003").mkdir()                                                   # no files: skipped with warnings
+    (tmp_path / ".hidden").mkdir()
+    ds = PatientDRRDataset(str(tmp_path), target_xray_size=8, target_volume_size=(6, 5, 4))
+    assert len(ds) == 2 and [os.path.basename(p) for p in ds.patient_folders] == ["p001", "p002"]
+    item = ds[0]
+    assert set(item) == {"drr_frontal", "drr_lateral", "drr_stacked", "ct_volume", "patient_id", "aligned"}
+    assert item["patient_id"] == "p001" and item["drr_stacked"].shape == (2, 1, 8, 8) and item["ct_volume"].shape == (1, 6, 5, 4)
+    exp_ct = (np.clip(ct, -200, 200) + 200) / 400 * 2 - 1
+    assert np.allclose(item["ct_volume"][0].numpy(), exp_ct, atol=1e-6)
+    assert np.allclose(item["drr_stacked"][0, 0].numpy(), frontal / 255 * 2 - 1, atol=1e-6)       # view 0 = frontal, / 255
+    assert np.allclose(item["drr_stacked"][1, 0].numpy(), lateral * 2 - 1, atol=1e-6)             # view 1 = lateral, max <= 1: no / 255
+    assert torch.equal(item["drr_frontal"], item["drr_stacked"][0]) and torch.equal(item["drr_lateral"], item["drr_stacked"][1])
+    assert ds[1]["patient_id"] == "p002"                                         # *_frontal / *_lateral naming
+    # resize paths: bilinear / trilinear, align_corners=False, applied BEFORE the window / scaling
+    big = PatientDRRDataset(str(tmp_path), target_xray_size=16, target_volume_size=(12, 10, 8), normalize_range=(0, 1), validate_alignment=False)[0]
+    exp = F.interpolate(torch.from_numpy(ct)[None, None], size=(12, 10, 8), mode="trilinear", align_corners=False)[0]
+    assert torch.allclose(big["ct_volume"], (exp.clamp(-200, 200) + 200) / 400, atol=1e-6)
+    expf = F.interpolate(torch.from_numpy(frontal)[None, None], size=(16, 16), mode="bilinear", align_corners=False)[0] / 255
+    assert torch.allclose(big["drr_frontal"], expf, atol=1e-6)
+    flipped = PatientDRRDataset(str(tmp_path), target_xray_size=8, target_volume_size=(6, 5, 4), flip_drrs_vertical=True)[0]
+    assert torch.equal(flipped["drr_frontal"], torch.flip(item["drr_frontal"], dims=[-2]))
+    rep = ds.get_alignment_report()
+    assert rep["total_validated"] == 2 and rep["passed"] + rep["failed"] == 2
+    # max_patients stops the scan
+    assert len(PatientDRRDataset(str(tmp_path), target_xray_size=8, target_volume_size=(6, 5, 4), max_patients=1)) == 1
+
+
+def test_unusable_data_path_raises_instead_of_training_on_phantoms(tmp_path):
+    """A data_path that is given but unusable is an error, as in the reference (utils/dataset.py:78-79); synthetic phantoms
+    are served only for data_path=None."""
+    from utils.dataset import PatientDRRDataset
+    with pytest.raises(ValueError, match="No valid patient folders"):
+        PatientDRRDataset(str(tmp_path / "does_not_exist"))
+    (tmp_path / "empty_patient").mkdir()
+    with pytest.raises(ValueError, match="No valid patient folders"):
+        PatientDRRDataset(str(tmp_path))
+    assert PatientDRRDataset(None, max_patients=2, target_xray_size=32, target_volume_size=(8, 8, 8)).synthetic
+
+
+def test_nifti_volume_without_nibabel_raises_at_read_time(tmp_path):
+    import numpy as np
+    from utils.dataset import PatientDRRDataset
+    rng = np.random.default_rng(8)
+    _write_patient(tmp_path, "q1", rng)
+    os.rename(tmp_path / "q1" / "q1.npy", tmp_path / "q1" / "q1.nii.gz")          # a NIfTI name: found, but unreadable without nibabel
+    ds = PatientDRRDataset(str(tmp_path), target_xray_size=8, target_volume_size=(6, 5, 4))
+    try:
+        import nibabel  # noqa: F401
+    except ImportError:
+        with pytest.raises(ImportError, match="nibabel"):
+            ds[0]
+
+
+def test_train_val_test_split_uses_the_reference_seed():
+    from utils.dataset import create_train_val_datasets
+    tr, va, te = create_train_val_datasets(None, max_patients=20, target_xray_size=32, target_volume_size=(8, 8, 8))
+    assert (len(tr), len(va), len(te)) == (16, 2, 2)
+    ref = torch.utils.data.random_split(range(20), [16, 2, 2], generator=torch.Generator().manual_seed(42))
+    assert list(tr.indices) == list(ref[0].indices) and sorted(tr.indices + va.indices + te.indices) == list(range(20))
+
+
+def test_checkpoint_resume_round_trip(tmp_path):
+    """save_checkpoint / load_checkpoint of the direct trainer (reference train_direct_4gpu.py:177-189, :273-298): the dict
+    holds the reference's keys, a resumed model + optimizer + scheduler continue bit for bit, a missing file raises."""
+    from direct_regression import train_direct_4gpu as T
+
+    def make():
+        torch.manual_seed(3)
+        m = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 2))
+        o = torch.optim.AdamW(m.parameters(), lr=1e-2, weight_decay=0.01)
+        return m, o, torch.optim.lr_scheduler.CosineAnnealingLR(o, T_max=10, eta_min=1e-6)
+
+    def step(m, o, s, x):
+        o.zero_grad()
+        m(x).pow(2).mean().backward()
+        o.step()
+        s.step()
+    x = torch.randn(4, 6)
+    m, o, s = make()
+    for _ in range(3):
+        step(m, o, s, x)
+    path = tmp_path / "checkpoint_epoch_3.pt"
+    T.save_checkpoint(path, 3, m, o, s, 21.5, 22.0, {"training": {"num_epochs": 10}})
+    ck = torch.load(path, weights_only=False)
+    assert set(ck) == {"epoch", "model_state_dict", "optimizer_state_dict", "scheduler_state_dict", "val_psnr", "best_psnr", "config"}
+    m2, o2, s2 = make()
+    start, best = T.load_checkpoint(str(path), m2, o2, s2, "cpu")
+    assert (start, best) == (4, 22.0) and s2.get_last_lr() == s.get_last_lr()
+    step(m, o, s, x)
+    step(m2, o2, s2, x)
+    for a, b in zip(m.parameters(), m2.parameters()):
+        assert torch.equal(a, b)
+    with pytest.raises(FileNotFoundError):
+        T.load_checkpoint(str(tmp_path / "nope.pt"), m2, o2, s2, "cpu")

@@ -199,3 +199,89 @@ def test_total_variation_loss(golden):
         loss.backward()
         g.check("", tag + "_grad", p.grad, RTOL)
     g.check("", "tv_flat", O.total_variation_loss(torch.full((1, 1, 4, 5, 6), 0.25)), RTOL)
+
+
+def frequency_loss_oracle(pred, target, high_freq_weight=2.0):
+    """FrequencyLoss.forward restated (direct_regression/progressive_cascade/loss_multiscale.py:203-236) in closed form:
+    (1/N) sum_f w_f | |P_f| - |T_f| |, w_f = 1 inside radius min(D,H,W)//4 of index (D//2,H//2,W//2), else the weight."""
+    P = torch.fft.fftn(pred.double(), dim=(-3, -2, -1)).abs()
+    T = torch.fft.fftn(target.double(), dim=(-3, -2, -1)).abs()
+    D, H, W = pred.shape[-3:]
+    dd, hh, ww = torch.meshgrid(torch.arange(D) - D // 2, torch.arange(H) - H // 2, torch.arange(W) - W // 2, indexing="ij")
+    high = (torch.sqrt((dd ** 2 + hh ** 2 + ww ** 2).double()) > min(D, H, W) // 4)
+    w = torch.where(high, torch.tensor(float(high_freq_weight), dtype=torch.float64), torch.tensor(1.0, dtype=torch.float64))
+    return ((P - T).abs() * w).mean()
+
+
+def test_frequency_loss_closed_form(golden):
+    g = golden("frequency")
+    for tag, w in (("w2", 2.0), ("w05", 0.5)):
+        p = g.t("pred").requires_grad_(True)
+        loss = frequency_loss_oracle(p, g.t("target"), w)
+        g.check("", f"loss_{tag}", loss, 1e-5)
+        loss.backward()
+        g.check("", f"grad_{tag}", p.grad, 1e-4)
+
+
+def test_sinusoidal_time_embedding(golden):
+    g = golden("time_embedding")
+    t = g.t("t")
+    # sin/cos of arguments up to ~1000 rad: fp32 argument rounding alone is 6e-5 absolute
+    assert torch.allclose(O.sinusoidal_time_embedding(t, 32), g.t("emb32"), rtol=0, atol=2e-4)
+    assert torch.allclose(O.sinusoidal_time_embedding(t, 256), g.t("emb256"), rtol=0, atol=2e-4)
+
+
+def test_train_step_two_steps(golden):
+    """The oracle driven through the reference's step (direct_regression/train_direct_4gpu.py:59-75) reproduces the
+    reference's loss, pre-clip gradient norm, clipped gradients and post-AdamW weights for two consecutive steps."""
+    g = golden("train_step")
+    cfg = [int(v) for v in g.z["cfg"]]
+    P = _req(g.group("params"))
+    leaves = {k: v for k, v in P.items() if v.requires_grad}
+    opt = torch.optim.AdamW(list(leaves.values()), lr=1e-4, weight_decay=0.01)
+    xr, target = g.t("xrays"), g.t("target")
+    for step in (1, 2):
+        opt.zero_grad()
+        stats = {}
+        before = {k: v.detach().clone() for k, v in leaves.items()}
+        pred = O.direct_ct_regression(xr, P, tuple(cfg[:3]), cfg[4], cfg[5], cfg[6], training=True, new_stats=stats)
+        loss = O.direct_regression_loss(pred, target)["total_loss"]
+        loss.backward()
+        norm = torch.nn.utils.clip_grad_norm_(list(leaves.values()), 1.0)
+        assert abs(loss.item() - float(g.z[f"step{step}_loss"])) < 1e-5
+        assert abs(norm.item() - float(g.z[f"step{step}_gradnorm"])) < 1e-4 * float(g.z[f"step{step}_gradnorm"])
+        for k, v in leaves.items():
+            if not _pre_bn_bias(k):
+                g.check(f"step{step}_clipped", k, v.grad, 1e-4)
+        opt.step()
+        with torch.no_grad():
+            for k, v in stats.items():
+                P[k].copy_(v)
+        for k, v in leaves.items():
+            # AdamW moves every weight by ~lr: compare the MOVE (sign-like on step 1), skipping the zero-gradient biases
+            if _pre_bn_bias(k):
+                continue
+            g.check_step_move("params" if step == 1 else "step1_after", f"step{step}_after", k, before[k], v, 1e-4, 0.0, 0.01) \
+                if step == 1 else None
+            g.check(f"step{step}_after", k, v, 1e-3)          # weights themselves, relative to max|w|
+        for k in stats:
+            g.check(f"step{step}_after", k, P[k], 1e-4)
+
+
+def test_xray_encoder_explicit_routing_is_the_same_function(golden):
+    """oracle._relu_pool: replaying an evaluation's own ReLU / max-pool routing reproduces its outputs and gradients,
+    so the routed form used by the GPU gradient test is the reference's function wherever the routing agrees."""
+    g = golden("xray_cond")
+    outs = []
+    route_use = None
+    for _ in range(2):
+        P = _req(g.group("train_params"))
+        xr = g.t("xrays").requires_grad_(True)
+        route = {} if route_use is None else {"use": route_use}
+        ctx, cond, feats = O.xray_conditioning(xr, g.t("t"), P, "", True, {}, route)
+        ((ctx * g.t("w_ctx")).sum() + (cond * g.t("w_cond")).sum() + (feats * g.t("w_f")).sum()).backward()
+        outs.append((feats.detach(), xr.grad.clone(), P["encoder.0.weight"].grad.clone()))
+        route_use = route["own"]
+    for a, b in zip(*outs):
+        assert torch.allclose(a, b, rtol=1e-6, atol=1e-7)
+    g.check("", "train_dxr", outs[1][1], RTOL * 5)
