@@ -28,11 +28,16 @@ def compute_dtype(ref: torch.Tensor) -> torch.dtype:
     return torch.float32
 
 
-# ---- weight casts are cached ON the parameter object, keyed by its version counter, device and storage address:
-# parameters change once per optimizer step, so the bf16 copies are refreshed once per step, not per use.  The key
-# covers optimizer steps, load_state_dict, `p.data = ...` and module.to(device) (new storage).  The one write it cannot
-# see is an IN-PLACE write through `.data` (p.data.mul_(..), EMA updates): same storage, and `.data` has its own version
-# counter -- call invalidate_param_casts() after such a write.
+# ---- weight casts are cached ON the parameter object, keyed by a global epoch, the tensor's version counter, device and
+# storage address: parameters change once per optimizer step, so the bf16 copies are refreshed once per step, not per use.
+#   * every torch optimizer's step() advances the epoch (global step post-hook below).  This is REQUIRED, not a nicety:
+#     the fused / foreach optimizer kernels (AdamW(fused=True), what the trainers and bench.py use) update parameters
+#     without bumping their version counters, so a version-only key would keep serving the pre-step weights for ever
+#     (found by the two-step train_step fixture: step 2 ran on step-0 conv weights);
+#   * the version counter covers load_state_dict, copy_ and other autograd-visible in-place writes;
+#   * device + storage address cover `p.data = ...` and module.to(device).
+# The one write nothing here can see is an IN-PLACE write through `.data` outside an optimizer (p.data.mul_(..), hand-written
+# EMA updates): same storage, `.data` has its own version counter -- call invalidate_param_casts() after such a write.
 _CAST_EPOCH = 0
 
 
@@ -45,6 +50,15 @@ def invalidate_param_casts():
 
 def _cache_key(p, *extra):
     return (p._version, _CAST_EPOCH, p.device, p.data_ptr(), *extra)
+
+
+def _after_optimizer_step(optimizer, args, kwargs):
+    invalidate_param_casts()
+
+
+from torch.optim.optimizer import register_optimizer_step_post_hook as _register_step_hook  # noqa: E402
+
+_register_step_hook(_after_optimizer_step)
 
 
 def cast_param(p: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:

@@ -309,3 +309,17 @@ def test_checkpoint_resume_round_trip(tmp_path):
         assert torch.equal(a, b)
     with pytest.raises(FileNotFoundError):
         T.load_checkpoint(str(tmp_path / "nope.pt"), m2, o2, s2, "cpu")
+
+
+def test_every_optimizer_step_invalidates_the_weight_cast_cache():
+    """AdamW(fused=True) updates parameters WITHOUT bumping their version counters, so the cached bf16 weight copies are
+    keyed by an epoch that every optimizer step advances (hvc/functional.py); without it training silently runs on the
+    pre-step weights."""
+    from hvc import functional as HF
+    p = torch.nn.Parameter(torch.randn(4, 4))
+    for kw in (dict(fused=True), dict(foreach=True), dict()):
+        opt = torch.optim.AdamW([p], lr=1e-3, **kw)
+        p.grad = torch.randn(4, 4)
+        key0 = HF._cache_key(p, torch.bfloat16)
+        opt.step()
+        assert HF._cache_key(p, torch.bfloat16) != key0, kw
