@@ -25,7 +25,6 @@
 // cross-workgroup reduction: dQ, dK, dV are bitwise reproducible.
 #include <cstdlib>
 #include <type_traits>
-#include <utility>
 
 #include "hvc_common.hip.h"
 #include "hvc_kernels.h"
@@ -1116,415 +1115,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a) 
         }
 }
 
-// ---------------------------------------------------------------------------------
-// backward: dK, dV -- 64 keys per wavefront, one wavefront per SIMD (bf16, 16-byte addressable operands)
-// ---------------------------------------------------------------------------------
-// Same mathematics and the same dropout lots as attn_bwd_dkv_kernel, re-tiled for the LDS pipe and for in-wave overlap:
-//   * workgroup = 4 wavefronts = 256 keys, ONE workgroup per CU (launch bound 1: 256 arch VGPRs + 256 accumulator
-//     registers per lane).  A wavefront holds two 32-key blocks, so every Q / dO fragment read from LDS (row fragments
-//     for S / dP, transposed fragments for dV / dK), every row constant and every tile load / commit / barrier serves
-//     two MFMAs instead of one.  dK / dV accumulators and the K / V fragments live in AGPRs (MFMA operands may), the
-//     arch VGPRs hold only what vector instructions touch.
-//   * the two key blocks of a wavefront are the EVEN and the ODD keys of its 64-key range: the two 16-bit dropout lots
-//     of keys 2r, 2r+1 share one dword of the lot tile, so one ds_read2_b32 brings the lots of two query rows for both
-//     blocks (8 reads per 32-query slice instead of 64 two-byte reads); block 0 tests the low half with a 16-bit
-//     compare, block 1 the whole word against ts << 16.  LDS instructions per MFMA: 3.3 -> 1.3.
-//   * the 64-query tile is processed as two 32-query slices whose phases alternate IN PROGRAM ORDER (a wavefront issues
-//     in order: MFMA / VALU overlap inside one wavefront exists only where the two kinds alternate in the stream):
-//         A(0) | A(1) + B(0) | C(0) + B(1) | C(1) + lots of the next tile | commit, barrier
-//     A = S / dP chains, B = exp / dropout select / dS (vector), C = dV / dK products; in the two middle phases each
-//     of the 16 MFMAs is followed by the vector work of one pair of elements of both blocks.
-//   * every MFMA is an asm statement: hipcc selects the AGPR form for every MFMA builtin once the budget exceeds 256
-//     registers (S / dP would then cost one v_accvgpr_read per value), and volatile asm pins the MFMAs' program
-//     positions.  Hazards hipcc does not pad around an asm MFMA (guide 5.7): s_nop 1 in front of the first MFMA of a chain
-//     (its accumulator may have just been written by a vector move); s_nop 10 behind the last MFMA of a chain group (8-pass
-//     XDL result -> VALU read needs 11 wait states; every earlier result is older by >= 1 MFMA); the C-phase operands need
-//     none: the P / dS fragments an MFMA reads were converted at least eight slots earlier (scheduling barriers close every
-//     slot, and a phase's first products take the k-step-0 fragments, written in the first half of the previous phase), the
-//     transposed fragments come from LDS reads the compiler waits for.
-constexpr int kKB2 = 256;                  // keys per workgroup
-
-template <typename F, int... I>
-__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
-template <int N, typename F>
-__device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
-constexpr int kLotStride2 = kKB2 + 8;      // 16-bit lots per tile row (528 bytes = 132 dwords: ds_read2_b32 reaches the next row)
-
-#define HVC_MFMA_VVA(acc, a, b) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(b))
-#define HVC_MFMA_VVA_FIRST(acc, a, b) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(b))
-#define HVC_MFMA_VVA_ZERO(acc, a, b) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "a"(b))
-#define HVC_MFMA_VVA_LAST(acc, a, b) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0\n\ts_nop 10" : "+v"(acc) : "v"(a), "a"(b))
-#define HVC_MFMA_AVV(acc, a, b) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b))
-
-template <int D, bool DROP>
-__global__ __launch_bounds__(256, 1) void attn_bwd_dkv2_kernel(const AttnArgs a) {
-    using T = bf16;
-    constexpr int TILE = kKT * D;
-    constexpr int DS = D / 16, DT = D / 32;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    bf16* lds = reinterpret_cast<bf16*>(smem);                       // [buf][Q|dO][TILE]
-    float* stat = reinterpret_cast<float*>(lds + 4 * TILE);          // [buf][lse2|delta|lse2 again][kKT]
-    uint16_t* lots = reinterpret_cast<uint16_t*>(stat + 2 * 3 * kKT);   // [buf][64 q][kLotStride2]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r = lane & 31, h = lane >> 5;
-
-    const int nkb = (a.Nk + kKB2 - 1) / kKB2;
-    const int nwg = nkb * a.B * a.H;
-    const int split = blockIdx.x / nwg;
-    int bh, kb;
-    block_map(blockIdx.x % nwg, a.B * a.H, nkb, bh, kb);
-    const int b = bh / a.H, hh = bh % a.H;
-    const T* qp = reinterpret_cast<const T*>(a.q) + b * a.q_sb + hh * a.q_sh;
-    const T* kp = reinterpret_cast<const T*>(a.k) + b * a.k_sb + hh * a.k_sh;
-    const T* vp = reinterpret_cast<const T*>(a.v) + b * a.v_sb + hh * a.v_sh;
-    const T* dop = reinterpret_cast<const T*>(a.dout) + b * a.do_sb + hh * a.do_sh;
-    T* dkp = reinterpret_cast<T*>(a.dk) + b * a.dk_sb + hh * a.dk_sh;
-    T* dvp = reinterpret_cast<T*>(a.dv) + b * a.dv_sb + hh * a.dv_sh;
-
-    const int k0 = kb * kKB2 + wave * 64;            // key of (block blk, tile column c) = k0 + 2 c + blk
-    const float sl2 = a.scale * kLog2e;
-    // K (pre-scaled: scores in exp2 units) and V row fragments go to AGPRs through LDS: ds_read_b128 may target AGPRs, while a
-    // value defined in a VGPR would be copied by four v_accvgpr_write in front of every MFMA naming it as an "a" operand.
-    bf16x8 kf[2][DS], vf[2][DS];
-    {
-        bf16x8* scr = reinterpret_cast<bf16x8*>(smem) + (size_t)wave * (4 * DS * 64) + lane;        // [frag][lane], 16 bytes each
-#pragma unroll
-        for (int blk = 0; blk < 2; ++blk) {
-            const int krow = k0 + 2 * r + blk;
-            const bool kvalid = krow < a.Nk;
-            const int krow_c = kvalid ? krow : a.Nk - 1;
-            bf16x8 kt[1][DS], vt[1][DS];
-            load_row_frags_scaled<T, 1, DS, true>(kp + (int64_t)krow_c * a.k_sn, h, kvalid, sl2, kt);
-            load_row_frags<T, 1, DS, true>(vp + (int64_t)krow_c * a.v_sn, h, kvalid, vt);
-#pragma unroll
-            for (int ks = 0; ks < DS; ++ks) {
-                scr[((blk * 2 + 0) * DS + ks) * 64] = kt[0][ks];
-                scr[((blk * 2 + 1) * DS + ks) * 64] = vt[0][ks];
-            }
-        }
-        const uint32_t scr_off = (uint32_t)(size_t)((__attribute__((address_space(3))) char*)reinterpret_cast<char*>(scr));
-#pragma unroll
-        for (int blk = 0; blk < 2; ++blk)
-#pragma unroll
-            for (int ks = 0; ks < DS; ++ks) {
-                // same-wave LDS operations complete in order: the reads see this wavefront's own stores
-                asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4\n\ts_waitcnt lgkmcnt(0)"
-                             : "=&a"(kf[blk][ks]), "=&a"(vf[blk][ks])
-                             : "v"(scr_off), "i"(((blk * 2 + 0) * DS + ks) * 1024), "i"(((blk * 2 + 1) * DS + ks) * 1024)
-                             : "memory");
-            }
-        __syncthreads();                          // the staging area is the tile / lots region
-    }
-
-    TileLoader<T, D, true> ql, dl;
-    auto Qt = [&](int buf) { return lds + (buf * 2 + 0) * TILE; };
-    auto Dt = [&](int buf) { return lds + (buf * 2 + 1) * TILE; };
-    const int nt_all = (a.Nq + kKT - 1) / kKT;
-    const int per_split = (nt_all + a.qsplit - 1) / a.qsplit;
-    const int t_begin = split * per_split;
-    const int nt = min(nt_all, t_begin + per_split);
-    float st_l = 0.f, st_d = 0.f;
-    auto issue_stat = [&](int t) {
-        if (tid < kKT) {
-            const int q = t * kKT + tid;
-            const bool ok = q < a.Nq;
-            st_l = ok ? -a.lse[(int64_t)bh * a.Nq + q] * kLog2e : -INFINITY;
-            st_d = ok ? -a.delta[(int64_t)bh * a.Nq + q] * (DROP ? 1.f / a.keep_scale : 1.f) : 0.f;
-        }
-    };
-    auto commit_stat = [&](int buf) {
-        if (tid < kKT) {
-            stat[(buf * 3 + 0) * kKT + tid] = st_l;
-            stat[(buf * 3 + 1) * kKT + tid] = st_d;
-            stat[(buf * 3 + 2) * kKT + tid] = st_l;      // second copy: each key block's S accumulator is seeded by its own LDS read
-        }
-    };
-    // dropout lots of tile t: thread -> (q row tid >> 2, 64-key quarter tid & 3 of the workgroup's 256 keys) = one 64-key hash
-    // tile, 16 groups of 4 keys, laid out by key as everywhere else; `part` = hashes [4 part, 4 part + 4), spread between MFMAs.
-    uint32_t lot_rk[2];
-    auto lots_begin = [&](int t) {
-        if constexpr (DROP) {
-            const int q = min(t * kKT + (tid >> 2), a.Nq - 1);
-            const uint32_t rk0 = drop_rowkey(a, bh, q), tadd = (uint32_t)(4 * kb + (tid & 3)) * kTileAdd;
-            lot_rk[0] = rk0 + tadd;
-            lot_rk[1] = (rk0 ^ kGrpH) + tadd;
-        }
-    };
-    auto lots_one = [&](auto u_tag, int buf) {                   // group j = u (4 keys) of the thread's hash tile
-        if constexpr (DROP) {
-            constexpr int u = decltype(u_tag)::value;
-            uint32_t* dst = reinterpret_cast<uint32_t*>(lots + ((size_t)buf * kKT + (tid >> 2)) * kLotStride2 + 64 * (tid & 3));
-            const uint32_t m = lot_rk[u & 1] ^ (drop_grp_a(u >> 3) ^ drop_grp_b((u >> 1) & 3));
-            drop_lots4(m, dst[2 * u], dst[2 * u + 1]);
-        }
-    };
-    using I0 = std::integral_constant<int, 0>;
-    using I1 = std::integral_constant<int, 1>;
-    ql.init(qp, a.q_sn, t_begin * kKT, tid);
-    dl.init(dop, a.do_sn, t_begin * kKT, tid);
-    ql.issue(qp, a.q_sn, t_begin * kKT, a.Nq, tid);
-    dl.issue(dop, a.do_sn, t_begin * kKT, a.Nq, tid);
-    issue_stat(t_begin);
-    ql.commit(Qt(t_begin & 1), tid);
-    dl.commit(Dt(t_begin & 1), tid);
-    commit_stat(t_begin & 1);
-    lots_begin(t_begin);
-    static_for<16>([&](auto u) { lots_one(u, t_begin & 1); });
-    __syncthreads();
-
-    const int ts = drop_ts(a);
-    const int ts_hi = ts * 65536;
-    f32x16 dk[2][DT], dv[2][DT];               // AGPR-resident ("+a" operands of the C-phase MFMAs)
-#pragma unroll
-    for (int blk = 0; blk < 2; ++blk)
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) { dk[blk][dt][i] = 0.f; dv[blk][dt][i] = 0.f; }
-
-    const bf16* raddr[DS];
-    const bf16* taddr[DT][2];
-#pragma unroll
-    for (int s = 0; s < DS; ++s) raddr[s] = lds + row_frag_lane_off<D>(16 * s, lane);
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt) {
-        int oa, ob;
-        tr_frag_lane_off<D, true>(32 * dt, lane, oa, ob);
-        taddr[dt][0] = lds + oa;
-        taddr[dt][1] = lds + ob;
-    }
-    const float* stat_lane = stat + 4 * h;
-    // dword (keys k0 + 2r, k0 + 2r + 1) of query row 4h (+ 8g + j + 32 qt) of the lot tile
-    const uint32_t* lots_lane = reinterpret_cast<const uint32_t*>(lots + 4 * h * kLotStride2 + wave * 64) + r;
-    constexpr int LROW = kLotStride2 / 2;      // lot-tile row stride in dwords
-
-    auto step = [&](auto buf_tag, int t) {
-        constexpr int buf = decltype(buf_tag)::value;
-        constexpr int QOFF = (buf * 2 + 0) * TILE, DOFF = (buf * 2 + 1) * TILE;
-        constexpr int NM = 4 * DS;                // MFMAs per phase (A: 4 per 16-wide d step; C: 4 per (16-query step, 32-wide d block))
-        constexpr int NQ = NM / 4;                // fragment groups ("quads") per phase; even
-        constexpr int HP = 16 / NM;               // vector half steps (and lot hashes) per MFMA slot
-        const bool more = t + 1 < nt;
-        if (more) {
-            ql.issue(qp, a.q_sn, (t + 1) * kKT, a.Nq, tid);
-            dl.issue(dop, a.do_sn, (t + 1) * kKT, a.Nq, tid);
-            issue_stat(t + 1);
-            lots_begin(t + 1);
-        }
-        f32x16 s[2][2], dp[2][2];                 // [slice][key block]
-        bf16x8 pf[2][2][2], dsf[2][2][2];         // [slice][key block][16-query k-step]
-        uint32_t lw[2][16];                       // [slice][query row (register index)]: the lots of both key blocks
-        f32x4 nd[2][4];                           // [slice][g]: -delta of query rows 8g + 4h + {0..3}
-        bf16x8 fa[2][2];                          // fragment ping-pong [parity][2]: Q, dO row fragments (A) / dO, Q transposed (C)
-        f32x2 hp[2], hpd[2];                      // a vector step's values between its two halves: p and dropped p of both blocks
-
-        // row constants and lot words of one slice: -lse2 seeds both S accumulators, -delta seeds dP (no dropout) or stays a
-        // multiplicand (dropout: dS = Pd dP + P (-delta), the dP chain then starts from the inline constant 0)
-        auto A_init = [&](auto qt_tag) {
-            constexpr int qt = decltype(qt_tag)::value;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int ro = 32 * qt + 8 * g;
-                // (the same four constants from two LDS copies, one read per accumulator: LDS has the headroom, register moves do not)
-                const f32x4 l4 = *reinterpret_cast<const f32x4*>(stat_lane + ((buf * 3 + 0) * kKT + ro));
-                const f32x4 l4b = *reinterpret_cast<const f32x4*>(stat_lane + ((buf * 3 + 2) * kKT + ro));
-                nd[qt][g] = *reinterpret_cast<const f32x4*>(stat_lane + ((buf * 3 + 1) * kKT + ro));
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    s[qt][0][4 * g + j] = l4[j]; s[qt][1][4 * g + j] = l4b[j];
-                    if constexpr (!DROP) { dp[qt][0][4 * g + j] = nd[qt][g][j]; dp[qt][1][4 * g + j] = nd[qt][g][j]; }
-                    if constexpr (DROP) lw[qt][4 * g + j] = lots_lane[(buf * kKT + ro + j) * LROW];
-                }
-            }
-        };
-        auto A_frags = [&](auto qt_tag, auto ks_tag) {          // row fragments of k-step ks -> fa[ks & 1]
-            constexpr int qt = decltype(qt_tag)::value, ks = decltype(ks_tag)::value;
-            fa[ks & 1][0] = *reinterpret_cast<const bf16x8*>(raddr[ks] + (QOFF + 32 * qt * D));
-            fa[ks & 1][1] = *reinterpret_cast<const bf16x8*>(raddr[ks] + (DOFF + 32 * qt * D));
-        };
-        auto C_frags = [&](auto qt_tag, auto qd_tag) {          // transposed fragments of quad qd = s2 * DT + dt -> fa[qd & 1]
-            constexpr int qt = decltype(qt_tag)::value, qd = decltype(qd_tag)::value;
-            constexpr int s2 = qd / DT, dt = qd % DT;
-            constexpr int TO = (32 * qt + 16 * s2) * D;
-            fa[qd & 1][0] = tr_frag_at(taddr[dt][0] + (DOFF + TO), taddr[dt][1] + (DOFF + TO));
-            fa[qd & 1][1] = tr_frag_at(taddr[dt][0] + (QOFF + TO), taddr[dt][1] + (QOFF + TO));
-        };
-        // MFMA n of phase A(qt): S[q][key] = Q K^T + (-lse2[q]),  dP[q][key] = dO V^T; key on the lane
-        auto A_mfma = [&](auto qt_tag, auto n_tag) {
-            constexpr int qt = decltype(qt_tag)::value, n = decltype(n_tag)::value;
-            constexpr int ks = n / 4, blk = (n % 4) / 2, is_dp = n & 1;
-            f32x16& acc = is_dp ? dp[qt][blk] : s[qt][blk];
-            const bf16x8& av = fa[ks & 1][is_dp];
-            const bf16x8& bv = is_dp ? vf[blk][ks] : kf[blk][ks];
-            if constexpr (ks == 0 && is_dp && DROP) HVC_MFMA_VVA_ZERO(acc, av, bv);
-            else if constexpr (ks == 0) HVC_MFMA_VVA_FIRST(acc, av, bv);
-            else if constexpr (n == NM - 1) HVC_MFMA_VVA_LAST(acc, av, bv);
-            else HVC_MFMA_VVA(acc, av, bv);
-        };
-        // MFMA n of phase C(qt): dV[key][d] += Pd^T dO, dK[key][d] += dS^T Q  (P / dS accumulator tiles as the A operand)
-        auto C_mfma = [&](auto qt_tag, auto n_tag) {
-            constexpr int qt = decltype(qt_tag)::value, n = decltype(n_tag)::value;
-            constexpr int qd = n / 4, s2 = qd / DT, dt = qd % DT, blk = (n % 4) / 2, is_dk = n & 1;
-            // (named references: clang does not treat an asm operand inside a nested generic lambda as a use that captures)
-            f32x16& acc = is_dk ? dk[blk][dt] : dv[blk][dt];
-            const bf16x8& av = is_dk ? dsf[qt][blk][s2] : pf[qt][blk][s2];
-            const bf16x8& bv = fa[qd & 1][is_dk];
-            HVC_MFMA_AVV(acc, av, bv);
-        };
-        // vector half step m (0..15) of slice qt: pair index m / 2 -> registers i, i + 1 (query rows) of BOTH key blocks.
-        //   first half : p = exp2(S'), dropout select;   second half : dS = Pd dP + P (-delta), bf16 fragments of the C phase
-        auto B_half = [&](auto qt_tag, auto m_tag) {
-            constexpr int qt = decltype(qt_tag)::value, m = decltype(m_tag)::value;
-            constexpr int pi = m / 2, g = pi / 2, jp = pi % 2, i = 4 * g + 2 * jp;
-            if constexpr ((m & 1) == 0) {
-#pragma unroll
-                for (int blk = 0; blk < 2; ++blk) {
-                    hp[blk][0] = __builtin_amdgcn_exp2f(s[qt][blk][i]);
-                    hp[blk][1] = __builtin_amdgcn_exp2f(s[qt][blk][i + 1]);
-                }
-                if constexpr (DROP) {
-                    // lots of rows i, i + 1: block 0 = low half (16-bit compare), block 1 = high half (whole word against ts << 16).
-                    // Four compares ahead of the four selects: a VALU-written mask needs two wait states before a VALU reads it.
-                    unsigned long long m0, m1, m2, m3;
-                    asm("v_cmp_ge_i16_e64 %[m0], %[w0], %[ts]\n\t"
-                        "v_cmp_ge_i16_e64 %[m1], %[w1], %[ts]\n\t"
-                        "v_cmp_ge_i32_e64 %[m2], %[w0], %[th]\n\t"
-                        "v_cmp_ge_i32_e64 %[m3], %[w1], %[th]\n\t"
-                        "v_cndmask_b32_e64 %[d0], 0, %[p0], %[m0]\n\t"
-                        "v_cndmask_b32_e64 %[d1], 0, %[p1], %[m1]\n\t"
-                        "v_cndmask_b32_e64 %[d2], 0, %[p2], %[m2]\n\t"
-                        "v_cndmask_b32_e64 %[d3], 0, %[p3], %[m3]"
-                        : [d0] "=&v"(hpd[0][0]), [d1] "=&v"(hpd[0][1]), [d2] "=&v"(hpd[1][0]), [d3] "=&v"(hpd[1][1]),
-                          [m0] "=&s"(m0), [m1] "=&s"(m1), [m2] "=&s"(m2), [m3] "=&s"(m3)
-                        : [w0] "v"(lw[qt][i]), [w1] "v"(lw[qt][i + 1]), [ts] "s"(ts), [th] "s"(ts_hi),
-                          [p0] "v"(hp[0][0]), [p1] "v"(hp[0][1]), [p2] "v"(hp[1][0]), [p3] "v"(hp[1][1]));
-                } else {
-                    hpd[0] = hp[0];
-                    hpd[1] = hp[1];
-                }
-            } else {
-#pragma unroll
-                for (int blk = 0; blk < 2; ++blk) {
-                    // plain single-lane-width f32 multiplies / fmas, as asm so that -O3 does not SLP-pack them: beside MFMAs at one
-                    // wave per SIMD a v_pk_fma_f32 costs ~22 cycles more than the two v_fma_f32 it replaces (MI355X guide, cycle table)
-                    float ds2[2];
-#pragma unroll
-                    for (int e = 0; e < 2; ++e) {
-                        if constexpr (DROP) {
-                            float t;
-                            asm("v_mul_f32_e32 %0, %1, %2" : "=v"(t) : "v"(hp[blk][e]), "v"(nd[qt][g][2 * jp + e]));
-                            asm("v_fma_f32 %0, %1, %2, %3" : "=v"(ds2[e]) : "v"(hpd[blk][e]), "v"(dp[qt][blk][i + e]), "v"(t));
-                        } else {
-                            asm("v_mul_f32_e32 %0, %1, %2" : "=v"(ds2[e]) : "v"(hp[blk][e]), "v"(dp[qt][blk][i + e]));
-                        }
-                    }
-                    pf[qt][blk][g >> 1][4 * (g & 1) + 2 * jp] = f2bf(hpd[blk][0]);
-                    pf[qt][blk][g >> 1][4 * (g & 1) + 2 * jp + 1] = f2bf(hpd[blk][1]);
-                    dsf[qt][blk][g >> 1][4 * (g & 1) + 2 * jp] = f2bf(ds2[0]);
-                    dsf[qt][blk][g >> 1][4 * (g & 1) + 2 * jp + 1] = f2bf(ds2[1]);
-                    // pin the conversions to THIS slot: volatile statements keep their order, so the MFMA that reads the fragment
-                    // (a volatile asm at least eight slots on) cannot have them sunk in front of it (VALU write -> MFMA read hazard)
-                    asm volatile("" : "+v"(pf[qt][blk][g >> 1]), "+v"(dsf[qt][blk][g >> 1]));
-                }
-            }
-        };
-        // Every slot = one MFMA + its vector filler, closed by a scheduling barrier: the MFMAs keep their program positions and
-        // the fillers stay between them; fragments are fetched one group (four MFMAs) ahead of their use.
-#define HVC_SB() __builtin_amdgcn_sched_barrier(0)
-        // ---- phase 1: slice 0 chains (nothing to overlap with yet); the LDS reads of both slices' row constants go first
-        A_init(I0{});
-        A_frags(I0{}, I0{});
-        A_init(I1{});
-        HVC_SB();
-        static_for<NM>([&](auto n) {
-            constexpr int N = decltype(n)::value;
-            if constexpr (N % 4 == 0) {
-                if constexpr (N / 4 + 1 < DS) A_frags(I0{}, std::integral_constant<int, N / 4 + 1>{});
-                else A_frags(I1{}, I0{});         // DS is even: slice 1's first k-step lands in fa[0]
-            }
-            A_mfma(I0{}, n);
-            HVC_SB();
-        });
-        // ---- phase 2: slice 1 chains, the vector work of slice 0 between the MFMAs
-        static_for<NM>([&](auto n) {
-            constexpr int N = decltype(n)::value;
-            if constexpr (N % 4 == 0) {
-                if constexpr (N / 4 + 1 < DS) A_frags(I1{}, std::integral_constant<int, N / 4 + 1>{});
-                else C_frags(I0{}, I0{});         // first transposed fragments of phase 3 -> fa[0]
-            }
-            A_mfma(I1{}, n);
-            static_for<HP>([&](auto e) { B_half(I0{}, std::integral_constant<int, N * HP + decltype(e)::value>{}); });
-            HVC_SB();
-        });
-        // ---- phase 3: slice 0 products, the vector work of slice 1 between the MFMAs
-        static_for<NM>([&](auto n) {
-            constexpr int N = decltype(n)::value;
-            if constexpr (N % 4 == 0) {
-                if constexpr (N / 4 + 1 < NQ) C_frags(I0{}, std::integral_constant<int, N / 4 + 1>{});
-                else C_frags(I1{}, I0{});         // NQ is even -> fa[0]
-            }
-            C_mfma(I0{}, n);
-            static_for<HP>([&](auto e) { B_half(I1{}, std::integral_constant<int, N * HP + decltype(e)::value>{}); });
-            HVC_SB();
-        });
-        // ---- phase 4: slice 1 products, the next tile's dropout lots between the MFMAs
-        static_for<NM>([&](auto n) {
-            constexpr int N = decltype(n)::value;
-            if constexpr (N % 4 == 0 && N / 4 + 1 < NQ) C_frags(I1{}, std::integral_constant<int, N / 4 + 1>{});
-            C_mfma(I1{}, n);
-            if (more) static_for<HP>([&](auto e) { lots_one(std::integral_constant<int, N * HP + decltype(e)::value>{}, buf ^ 1); });
-            HVC_SB();
-        });
-#undef HVC_SB
-        if (more) {
-            ql.commit(Qt(buf ^ 1), tid);
-            dl.commit(Dt(buf ^ 1), tid);
-            commit_stat(buf ^ 1);
-        }
-        __syncthreads();
-    };
-    {
-        int t = t_begin;
-        if (t < nt && (t & 1)) { step(I1{}, t); ++t; }
-        for (; t + 1 < nt; t += 2) {
-            step(I0{}, t);
-            step(I1{}, t + 1);
-        }
-        if (t < nt) step(I0{}, t);
-    }
-    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");      // last asm MFMA -> the compiler's accumulator reads below
-    const float ksc = DROP ? a.keep_scale : 1.f;
-#pragma unroll
-    for (int blk = 0; blk < 2; ++blk) {
-        if (a.qsplit > 1) {
-            const size_t slab = (size_t)a.B * a.H * a.Nk * D;
-            float* pk = a.dkv_partial + ((size_t)split * a.B * a.H + bh) * a.Nk * D;
-            float* pv = pk + (size_t)a.qsplit * slab;
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int kk = k0 + 2 * acc_row(i, h) + blk;
-                    if (kk < a.Nk) {
-                        pk[(size_t)kk * D + 32 * dt + r] = dk[blk][dt][i] * a.scale * ksc;
-                        pv[(size_t)kk * D + 32 * dt + r] = dv[blk][dt][i] * ksc;
-                    }
-                }
-        } else {
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int kk = k0 + 2 * acc_row(i, h) + blk;
-                    if (kk < a.Nk) {
-                        dkp[(int64_t)kk * a.dk_sn + 32 * dt + r] = from_f<T>(dk[blk][dt][i] * a.scale * ksc);
-                        dvp[(int64_t)kk * a.dv_sn + 32 * dt + r] = from_f<T>(dv[blk][dt][i] * ksc);
-                    }
-                }
-        }
-    }
-}
-
 // dK / dV = sum over the query-range slices of the partial slabs (fixed order), cast and scattered to the strided outputs
 template <typename T, int D>
 __global__ __launch_bounds__(256) void attn_dkv_reduce_kernel(const AttnArgs a) {
@@ -1542,24 +1132,6 @@ __global__ __launch_bounds__(256) void attn_dkv_reduce_kernel(const AttnArgs a) 
         reinterpret_cast<T*>(a.dk)[b * a.dk_sb + hh * a.dk_sh + (int64_t)key * a.dk_sn + d] = from_f<T>(sk);
         reinterpret_cast<T*>(a.dv)[b * a.dv_sb + hh * a.dv_sh + (int64_t)key * a.dv_sn + d] = from_f<T>(sv);
     }
-}
-
-// query-range slices per key block: few key blocks (cross-attention, small contexts) leave most CUs idle
-int dkv1_qsplit(int B, int H, int Nq, int Nk) {
-    const int wgs = ((Nk + kQB - 1) / kQB) * B * H;
-    const int nt = (Nq + kKT - 1) / kKT;
-    if (wgs >= 512 || nt < 16) return 1;
-    int want = (512 + wgs - 1) / wgs;          // the kernel runs two workgroups per CU: fill 512 slots in whole rounds (768 left half a round idle)
-    if (want > nt / 8) want = nt / 8;          // >= 8 query tiles per slice
-    return want < 2 ? 1 : want;
-}
-int dkv2_qsplit(int B, int H, int Nq, int Nk) {
-    const int wgs = ((Nk + kKB2 - 1) / kKB2) * B * H;
-    const int nt = (Nq + kKT - 1) / kKT;
-    if (wgs >= 256 || nt < 16) return 1;
-    int want = (256 + wgs - 1) / wgs;          // one workgroup per CU
-    if (want > nt / 8) want = nt / 8;
-    return want < 2 ? 1 : want;
 }
 
 template <typename T, int D>
@@ -1606,36 +1178,7 @@ hipError_t launch_bwd(const AttnArgs& a, hipStream_t st) {
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
-    bool done_dkv = false;
-    if constexpr (sizeof(T) == 2 && VEC) {
-        const char* env = getenv("HVC_ATTN_DKV");               // "1" / "2": pin the dK/dV kernel (parity tests run both)
-        const int force = env ? atoi(env) : 0;
-        if ((ph & 2) && force != 1) {
-            const int nkb = (a.Nk + kKB2 - 1) / kKB2;
-            size_t lds = (size_t)4 * kKT * D * sizeof(bf16) + 6 * kKT * sizeof(float) + (DROP ? (size_t)2 * kKT * kLotStride2 * sizeof(uint16_t) : 0);
-            const size_t staging = (size_t)4 * (4 * (D / 16) * 64) * 16;      // K / V fragments pass through LDS once (4 waves x 4 D/16 fragments x 64 lanes x 16 B)
-            if (lds < staging) lds = staging;
-            auto k = attn_bwd_dkv2_kernel<D, DROP>;
-            hipError_t e = set_lds(k, lds);
-            if (e != hipSuccess) return e;
-            AttnArgs b = a;
-            b.qsplit = dkv2_qsplit(a.B, a.H, a.Nq, a.Nk);
-            if (b.qsplit > 1 && (!a.dkv_partial || a.partial_floats < (int64_t)2 * b.qsplit * a.B * a.H * a.Nk * D)) b.qsplit = 1;
-            hipLaunchKernelGGL(k, dim3(nkb * a.B * a.H * b.qsplit), dim3(256), lds, st, b);
-            e = hipGetLastError();
-            if (e != hipSuccess) return e;
-            if (b.qsplit > 1) {
-                size_t n = (size_t)a.B * a.H * a.Nk * D;
-                int blocks = (int)((n + 255) / 256);
-                if (blocks > 4096) blocks = 4096;
-                hipLaunchKernelGGL((attn_dkv_reduce_kernel<T, D>), dim3(blocks), dim3(256), 0, st, b);
-                e = hipGetLastError();
-                if (e != hipSuccess) return e;
-            }
-            done_dkv = true;
-        }
-    }
-    if ((ph & 2) && !done_dkv) {
+    if (ph & 2) {
         const int nkb = (a.Nk + kQB - 1) / kQB;
         const size_t lds = dkv_lds_bytes<T, D>(DROP);
         auto k = attn_bwd_dkv_kernel<T, D, DROP, VEC>;
@@ -1644,7 +1187,7 @@ hipError_t launch_bwd(const AttnArgs& a, hipStream_t st) {
         // Few key blocks (cross-attention, small contexts) leave most CUs idle: slice the query range over more
         // workgroups and sum the fp32 partial dK / dV slabs in a second, deterministic pass.
         AttnArgs b = a;
-        b.qsplit = dkv1_qsplit(a.B, a.H, a.Nq, a.Nk);
+        b.qsplit = attention_bwd_qsplit(a.B, a.H, a.Nq, a.Nk);
         if (b.qsplit > 1 && (!a.dkv_partial || a.partial_floats < (int64_t)2 * b.qsplit * a.B * a.H * a.Nk * D)) b.qsplit = 1;
         hipLaunchKernelGGL(k, dim3(nkb * a.B * a.H * b.qsplit), dim3(256), lds, st, b);
         e = hipGetLastError();
@@ -1686,10 +1229,13 @@ hipError_t dispatch(const AttnArgs& a, bool bwd, hipStream_t st) {
 
 }  // namespace
 
-// workspace sizing (hvc_attention_bwd_workspace): the larger need of the two dK/dV kernels
 int attention_bwd_qsplit(int B, int H, int Nq, int Nk) {
-    const int q1 = dkv1_qsplit(B, H, Nq, Nk), q2 = dkv2_qsplit(B, H, Nq, Nk);
-    return q1 > q2 ? q1 : q2;
+    const int wgs = ((Nk + kQB - 1) / kQB) * B * H;
+    const int nt = (Nq + kKT - 1) / kKT;
+    if (wgs >= 512 || nt < 16) return 1;
+    int want = (512 + wgs - 1) / wgs;          // the kernel runs two workgroups per CU: fill 512 slots in whole rounds (768 left half a round idle)
+    if (want > nt / 8) want = nt / 8;          // >= 8 query tiles per slice
+    return want < 2 ? 1 : want;
 }
 
 hipError_t attention_launch(const AttnArgs& a, bool bwd, hipStream_t st) {
