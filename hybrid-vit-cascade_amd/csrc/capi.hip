@@ -477,4 +477,72 @@ int hvc_spectral_l1_bwd(const float* pred_spec, const float* target_spec, const 
     return hip_result(hvc::spec_l1_bwd_launch(a, (hipStream_t)stream), "spectral_l1_bwd");
 }
 
+int64_t hvc_resize_loss_workspace(int B, int S1, int S2) {
+    if (B < 1 || S1 < 1 || S2 < 1) return -1;
+    return hvc::resize_loss_blocks(B, S1, S2);
+}
+
+static int fill_resize_loss(hvc::ResizeLossArgs& a, const float* proj, const float* target, int B, int h, int w, int S1, int S2, int64_t tb,
+                            int align_corners, int mode) {
+    if (!proj || !target) return fail(HVC_E_BADARG, "resize_loss: null operand");
+    if (B < 1 || h < 1 || w < 1 || S1 < 1 || S2 < 1 || tb < (int64_t)S1 * S2) return fail(HVC_E_BADARG, "resize_loss: bad geometry");
+    if (mode < 0 || mode > 1) return fail(HVC_E_BADARG, "resize_loss: mode is 0 (L1) or 1 (MSE)");
+    memset(&a, 0, sizeof(a));
+    a.proj = proj; a.target = target; a.B = B; a.h = h; a.w = w; a.S1 = S1; a.S2 = S2; a.target_bstride = tb;
+    a.align_corners = align_corners ? 1 : 0; a.mode = mode;
+    return 0;
+}
+
+int hvc_resize_loss_fwd(const float* proj, const float* target, float* out1, float* workspace, int B, int h, int w, int S1, int S2,
+                        int64_t target_bstride, int align_corners, int mode, void* stream) {
+    hvc::ResizeLossArgs a;
+    int rc = fill_resize_loss(a, proj, target, B, h, w, S1, S2, target_bstride, align_corners, mode);
+    if (rc) return rc;
+    if (!out1 || !workspace) return fail(HVC_E_BADARG, "resize_loss_fwd: null output");
+    a.out = out1; a.workspace = workspace;
+    return hip_result(hvc::resize_loss_fwd_launch(a, (hipStream_t)stream), "resize_loss_fwd");
+}
+
+int hvc_resize_loss_grad(const float* proj, const float* target, const float* gscale, float* dresized, int B, int h, int w, int S1, int S2,
+                         int64_t target_bstride, int align_corners, int mode, void* stream) {
+    hvc::ResizeLossArgs a;
+    int rc = fill_resize_loss(a, proj, target, B, h, w, S1, S2, target_bstride, align_corners, mode);
+    if (rc) return rc;
+    if (!gscale || !dresized) return fail(HVC_E_BADARG, "resize_loss_grad: null operand");
+    a.gscale = gscale; a.dres = dresized;
+    return hip_result(hvc::resize_loss_grad_launch(a, (hipStream_t)stream), "resize_loss_grad");
+}
+
+int64_t hvc_view_mean_gap_workspace(int B, int P, int E) {
+    if (B < 1 || P < 1 || E < 1) return -1;
+    return (int64_t)B * hvc::view_gap_chunks(P) * E;
+}
+
+static int fill_view_gap(hvc::ViewGapArgs& a, int B, int V, int P, int E, int dtype) {
+    if (B < 1 || V < 1 || P < 1 || E < 8 || (E % 8) != 0 || E > 2048 || (256 % (E / 8)) != 0)
+        return fail(HVC_E_BADARG, "view_mean_gap: bad geometry (E / 8 must divide 256)");
+    if (!dtype_ok(dtype)) return fail(HVC_E_BADARG, "view_mean_gap: bad dtype");
+    memset(&a, 0, sizeof(a));
+    a.B = B; a.V = V; a.P = P; a.E = E; a.is_bf16 = dtype == HVC_BF16;
+    return 0;
+}
+
+int hvc_view_mean_gap_fwd(const void* feats, float* mean, float* pooled, float* workspace, int B, int V, int P, int E, int dtype, void* stream) {
+    hvc::ViewGapArgs a;
+    int rc = fill_view_gap(a, B, V, P, E, dtype);
+    if (rc) return rc;
+    if (!feats || !mean || !pooled || !workspace || !aligned16(feats) || !aligned16(mean)) return fail(HVC_E_BADARG, "view_mean_gap_fwd: null / unaligned operand");
+    a.f = feats; a.mean = mean; a.pooled = pooled; a.workspace = workspace;
+    return hip_result(hvc::view_mean_gap_fwd_launch(a, (hipStream_t)stream), "view_mean_gap_fwd");
+}
+
+int hvc_view_mean_gap_bwd(const float* dmean, const float* dpooled, void* dfeats, int B, int V, int P, int E, int dtype, void* stream) {
+    hvc::ViewGapArgs a;
+    int rc = fill_view_gap(a, B, V, P, E, dtype);
+    if (rc) return rc;
+    if (!dfeats || (!dmean && !dpooled) || !aligned16(dfeats)) return fail(HVC_E_BADARG, "view_mean_gap_bwd: null / unaligned operand");
+    a.dmean = dmean; a.dpooled = dpooled; a.df = dfeats;
+    return hip_result(hvc::view_mean_gap_bwd_launch(a, (hipStream_t)stream), "view_mean_gap_bwd");
+}
+
 }  // extern "C"

@@ -203,4 +203,34 @@ struct SpecArgs {
 hipError_t spec_l1_fwd_launch(const SpecArgs& a, hipStream_t st);
 hipError_t spec_l1_bwd_launch(const SpecArgs& a, hipStream_t st);
 
+struct ResizeLossArgs {
+    const float* proj;       // (B, h, w) fp32 contiguous
+    const float* target;     // (B, S1, S2) fp32, rows contiguous, batch stride target_bstride elements
+    float* out;              // [1] mean |r - t| (mode 0) or mean (r - t)^2 (mode 1)
+    float* workspace;        // resize_loss_blocks(B, S1, S2) floats
+    const float* gscale;     // device [1]: upstream gradient of the scalar
+    float* dres;             // (B, S1, S2): d loss / d resized image (input of the resize adjoint)
+    int B, h, w, S1, S2;
+    int64_t target_bstride;
+    int align_corners, mode;
+};
+int resize_loss_blocks(int B, int S1, int S2);
+hipError_t resize_loss_fwd_launch(const ResizeLossArgs& a, hipStream_t st);
+hipError_t resize_loss_grad_launch(const ResizeLossArgs& a, hipStream_t st);
+
+struct ViewGapArgs {
+    const void* f;           // (B*V, P, E) channels-last feature maps, fp32 or bf16
+    float* mean;             // (B, P, E) fp32: mean over the V views
+    float* pooled;           // (B, E) fp32: mean over P of `mean`
+    float* workspace;        // B * view_gap_chunks(P) * E floats
+    const float* dmean;      // bwd: (B, P, E) or null
+    const float* dpooled;    // bwd: (B, E) or null
+    void* df;                // bwd: (B*V, P, E) in the dtype of f
+    int B, V, P, E;
+    int is_bf16;
+};
+int view_gap_chunks(int P);
+hipError_t view_mean_gap_fwd_launch(const ViewGapArgs& a, hipStream_t st);
+hipError_t view_mean_gap_bwd_launch(const ViewGapArgs& a, hipStream_t st);
+
 }  // namespace hvc

@@ -16,7 +16,8 @@ _PKG = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 if _PKG not in sys.path:
     sys.path.insert(0, _PKG)
 
-from hvc import functional as HF  # noqa: E402
+from hvc import functional as HF
+from hvc import stem as HS  # noqa: E402
 
 
 def _l1(pred, target):
@@ -84,18 +85,27 @@ class DRRReprojectionLoss(nn.Module):
         super().__init__()
         self.img_size = img_size
 
-    def generate_drr(self, ct_volume, view_angle=0):
+    @staticmethod
+    def _project(ct_volume, view_angle):
         vol = ct_volume.squeeze(1).float()
         if view_angle == 0:
-            drr = HF.drr_project(vol, 0, exp_mode=False, out_scale=1.0 / vol.shape[1])
-        else:
-            drr = HF.drr_project(vol, 2, exp_mode=False, out_scale=1.0 / vol.shape[3])
-        return F.interpolate(drr.unsqueeze(1), size=(self.img_size, self.img_size), mode="bilinear", align_corners=False)
+            return HF.drr_project(vol, 0, exp_mode=False, out_scale=1.0 / vol.shape[1])          # mean over D -> (B, H, W)
+        return HF.drr_project(vol, 2, exp_mode=False, out_scale=1.0 / vol.shape[3])              # mean over W -> (B, D, H)
+
+    def generate_drr(self, ct_volume, view_angle=0):
+        """(B,1,img,img) mean projection (reference :250-273): HIP ray-sum + HIP bilinear resize (the resize kernel at depth 1)."""
+        drr = self._project(ct_volume, view_angle)
+        return HS.upsample_trilinear(drr.unsqueeze(1).unsqueeze(1), (1, self.img_size, self.img_size), align_corners=False).squeeze(1)
 
     def forward(self, pred_volume, input_xrays):
-        ap = self.generate_drr(pred_volume, 0)
-        lat = self.generate_drr(pred_volume, 90)
-        return (_l1(ap, input_xrays[:, 0]) + _l1(lat, input_xrays[:, 1])) / 2
+        # resize + L1 against each view fused in one pass per view; the X-ray views are read in place (no slicing copies)
+        losses = []
+        for v, angle in ((0, 0), (1, 90)):
+            target = input_xrays[:, v, 0]                     # (B, S, S) view: batch stride 2 S^2, rows contiguous
+            if tuple(target.shape[-2:]) != (self.img_size, self.img_size):
+                raise ValueError("DRRReprojectionLoss: the X-rays must be img_size x img_size")
+            losses.append(HF.ResizeLossFn.apply(self._project(pred_volume, angle), target, False, 0))
+        return (losses[0] + losses[1]) / 2
 
 
 class Stage1Loss(nn.Module):

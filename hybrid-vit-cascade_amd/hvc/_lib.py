@@ -54,6 +54,12 @@ SIGNATURES = {
     "hvc_spectral_l1_workspace": (_i64, [_i, _i, _i, _i]),
     "hvc_spectral_l1_fwd": (_i, [_p] * 4 + [_i] * 4 + [_p]),
     "hvc_spectral_l1_bwd": (_i, [_p] * 4 + [_i] * 4 + [_p]),
+    "hvc_resize_loss_workspace": (_i64, [_i, _i, _i]),
+    "hvc_resize_loss_fwd": (_i, [_p] * 4 + [_i] * 5 + [_i64, _i, _i, _p]),
+    "hvc_resize_loss_grad": (_i, [_p] * 4 + [_i] * 5 + [_i64, _i, _i, _p]),
+    "hvc_view_mean_gap_workspace": (_i64, [_i, _i, _i]),
+    "hvc_view_mean_gap_fwd": (_i, [_p] * 4 + [_i] * 5 + [_p]),
+    "hvc_view_mean_gap_bwd": (_i, [_p] * 3 + [_i] * 5 + [_p]),
     "hvc_drr_fwd": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _f, _f, _f, _i, _i, _p]),
     "hvc_drr_bwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _f, _f, _i, _i, _p]),
 }

@@ -30,15 +30,20 @@ def compute_dtype(ref: torch.Tensor) -> torch.dtype:
 
 # ---- weight casts are cached ON the parameter object, keyed by a global epoch, the tensor's version counter, device and
 # storage address: parameters change once per optimizer step, so the bf16 copies are refreshed once per step, not per use.
-#   * every torch optimizer's step() advances the epoch (global step post-hook below).  This is REQUIRED, not a nicety:
-#     the fused / foreach optimizer kernels (AdamW(fused=True), what the trainers and bench.py use) update parameters
-#     without bumping their version counters, so a version-only key would keep serving the pre-step weights for ever
-#     (found by the two-step train_step fixture: step 2 ran on step-0 conv weights);
+#   * every torch optimizer's step() advances the epoch and refreshes every registered copy IN PLACE with one multi-tensor
+#     cast (global step post-hook below).  This is REQUIRED, not a nicety: the fused / foreach optimizer kernels
+#     (AdamW(fused=True), what the trainers and bench.py use) update parameters without bumping their version counters, so a
+#     version-only key would keep serving the pre-step weights for ever (found by the two-step train_step fixture: step 2
+#     ran on step-0 conv weights).  One batched refresh instead of ~60 lazy per-tensor casts matters where the step is
+#     launch-bound (64^3: 12 ms of ~300 launches);
 #   * the version counter covers load_state_dict, copy_ and other autograd-visible in-place writes;
 #   * device + storage address cover `p.data = ...` and module.to(device).
 # The one write nothing here can see is an IN-PLACE write through `.data` outside an optimizer (p.data.mul_(..), hand-written
 # EMA updates): same storage, `.data` has its own version counter -- call invalidate_param_casts() after such a write.
+import weakref
+
 _CAST_EPOCH = 0
+_CAST_REGISTRY = {}          # id(param) -> (weakref(param), attribute name); entries die with their parameter
 
 
 def invalidate_param_casts():
@@ -46,14 +51,49 @@ def invalidate_param_casts():
     which does not bump the tensor version counter)."""
     global _CAST_EPOCH
     _CAST_EPOCH += 1
+    _CAST_REGISTRY.clear()
 
 
 def _cache_key(p, *extra):
     return (p._version, _CAST_EPOCH, p.device, p.data_ptr(), *extra)
 
 
+def _register(p, attr):
+    pid = id(p)
+    _CAST_REGISTRY[(pid, attr)] = (weakref.ref(p, lambda _r, k=(pid, attr): _CAST_REGISTRY.pop(k, None)), attr)
+
+
+def _conv_w2d_fill(dst, w):
+    """dst (Cout, Kp) <- w (Cout, Cin, *k) with column = tap * Cin + c (zero pad columns stay untouched)."""
+    cout, cin = w.shape[0], w.shape[1]
+    taps = w[0, 0].numel()
+    dst[:, :taps * cin].view(cout, taps, cin).copy_(w.detach().reshape(cout, cin, taps).permute(0, 2, 1))
+
+
 def _after_optimizer_step(optimizer, args, kwargs):
-    invalidate_param_casts()
+    """Refresh every live cached copy from its (just updated) parameter: plain casts in ONE multi-tensor copy, conv layouts
+    by one strided cast each; entries whose parameter moved (device / storage) or vanished are dropped and rebuilt lazily."""
+    global _CAST_EPOCH
+    _CAST_EPOCH += 1
+    srcs, dsts, rekey = [], [], []
+    for key, (ref, attr) in list(_CAST_REGISTRY.items()):
+        p = ref()
+        hit = getattr(p, attr, None) if p is not None else None
+        if hit is None or hit[0][2] != p.device or hit[0][3] != p.data_ptr() or not p.is_cuda:
+            _CAST_REGISTRY.pop(key, None)
+            continue
+        old_key, dst = hit
+        if attr == "_hvc_cast":
+            srcs.append(p.detach())
+            dsts.append(dst)
+        else:
+            _conv_w2d_fill(dst, p)
+        rekey.append((p, attr, old_key, dst))
+    if dsts:
+        with torch.no_grad():
+            torch._foreach_copy_(dsts, srcs)
+    for p, attr, old_key, dst in rekey:
+        setattr(p, attr, (_cache_key(p, *old_key[4:]), dst))
 
 
 from torch.optim.optimizer import register_optimizer_step_post_hook as _register_step_hook  # noqa: E402
@@ -72,6 +112,7 @@ def cast_param(p: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     out = ops.cast(p.detach(), dtype)
     try:
         p._hvc_cast = (key, out)
+        _register(p, "_hvc_cast")
     except AttributeError:
         pass
     return out
@@ -372,19 +413,17 @@ def drr_project(vol, axis, *, exp_mode, mu=0.3, out_scale=1.0, clamp_min=float("
 # conv stems on channels-last activations, normalisation, resize, loss
 # --------------------------------------------------------------------------------------------
 def conv_weight_2d(weight: torch.Tensor, dtype: torch.dtype, Kp: int) -> torch.Tensor:
-    """(Cout, Cin, *k) parameter -> GEMM operand (Cout, Kp), column = tap * Cin + c; cached per version."""
+    """(Cout, Cin, *k) parameter -> GEMM operand (Cout, Kp), column = tap * Cin + c; cached per version / optimizer step."""
     key = _cache_key(weight, dtype, Kp)
     hit = getattr(weight, "_hvc_w2d", None)
     if hit is not None and hit[0] == key:
         return hit[1]
-    w = weight.detach()
-    cout, cin = w.shape[0], w.shape[1]
-    w2 = w.reshape(cout, cin, -1).permute(0, 2, 1).reshape(cout, -1)      # (Cout, taps*Cin)
-    if w2.shape[1] != Kp:
-        w2 = torch.nn.functional.pad(w2, (0, Kp - w2.shape[1]))
-    w2 = ops.cast(w2.contiguous(), dtype) if dtype != w2.dtype else w2.contiguous()
+    w2 = torch.zeros((weight.shape[0], Kp), dtype=dtype, device=weight.device)
+    with torch.no_grad():
+        _conv_w2d_fill(w2, weight)
     try:
         weight._hvc_w2d = (key, w2)
+        _register(weight, "_hvc_w2d")
     except AttributeError:
         pass
     return w2
@@ -617,3 +656,47 @@ class SpectralL1Fn(torch.autograd.Function):
     def backward(ctx, dout):
         p, t = ctx.saved_tensors
         return ops.spectral_l1_bwd(p, t, _f32(dout)), None
+
+
+class ResizeLossFn(torch.autograd.Function):
+    """mean |bilinear(proj) - target| (mode 0) or mean squared difference (mode 1) without materialising the resized image
+    (tails of DRRReprojectionLoss, loss_multiscale.py:269-293, and ProjectionLoss, models/diagnostic_losses.py:161-169)."""
+
+    @staticmethod
+    def forward(ctx, proj, target, align_corners, mode):
+        p = _f32(proj)
+        t = target.detach()
+        if t.dtype != torch.float32:
+            t = t.float()
+        ctx.save_for_backward(p, t)
+        ctx.cfg = (bool(align_corners), int(mode), proj.dtype)
+        return ops.resize_loss_fwd(p, t, align_corners, mode)[0]
+
+    @staticmethod
+    def backward(ctx, dout):
+        p, t = ctx.saved_tensors
+        ac, mode, dtype = ctx.cfg
+        dres = ops.resize_loss_grad(p, t, _f32(dout).reshape(1), ac, mode)
+        B, h, w = p.shape
+        dp = ops.trilinear_bwd(dres.view(B, 1, *dres.shape[1:]), (1, h, w), ac).view(B, h, w)      # adjoint of the resize, depth 1
+        return (dp if dp.dtype == dtype else dp.to(dtype)), None, None, None
+
+
+class ViewMeanGapFn(torch.autograd.Function):
+    """Mean over the V views of the channels-last X-ray feature maps + global average pool, one pass
+    (models/diagnostic_losses.py:126, :131).  feats (B*V, P, E) -> (B, P, E) fp32, (B, E) fp32."""
+
+    @staticmethod
+    def forward(ctx, feats, V):
+        f = feats.detach().contiguous()
+        ctx.cfg = (V, f.dtype)
+        return ops.view_mean_gap_fwd(f, V)
+
+    @staticmethod
+    def backward(ctx, dmean, dpooled):
+        V, dtype = ctx.cfg
+        if dmean is None:
+            dmean = torch.zeros((dpooled.shape[0], 1, 1), device=dpooled.device)     # never the case on the hot path
+            raise RuntimeError("ViewMeanGapFn: the feature-map gradient is required")
+        df = ops.view_mean_gap_bwd(_f32(dmean), None if dpooled is None else _f32(dpooled), V, dtype)
+        return df, None

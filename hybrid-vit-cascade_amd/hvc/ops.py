@@ -524,3 +524,63 @@ def spectral_l1_bwd(pred_spec, target_spec, gscale):
     check(_lib.load().hvc_spectral_l1_bwd(pred_spec.data_ptr(), target_spec.data_ptr(), _ptr(_f32c(gscale, "gscale")), d.data_ptr(),
                                           B, D, H, W, _stream()), "hvc_spectral_l1_bwd")
     return d
+
+
+def resize_loss_fwd(proj, target, align_corners, mode):
+    """proj (B, h, w) fp32 contiguous; target (B, S1, S2) fp32 view with contiguous rows (batch stride free) -> scalar (1,)
+    mean |resize(proj) - target| (mode 0) or mean squared difference (mode 1)."""
+    _dev(proj, target)
+    _f32c(proj, "proj")
+    if target.dtype != torch.float32 or target.dim() != 3 or target.shape[0] != proj.shape[0] or target.stride(2) != 1 \
+            or (target.shape[1] > 1 and target.stride(1) != target.shape[2]):
+        raise ValueError("resize_loss: target must be a float32 (B, S1, S2) view with contiguous rows")
+    B, h, w = proj.shape
+    S1, S2 = target.shape[1], target.shape[2]
+    tb = target.stride(0) if B > 1 else S1 * S2
+    lib = _lib.load()
+    ws = torch.empty((lib.hvc_resize_loss_workspace(B, S1, S2),), dtype=torch.float32, device=proj.device)
+    out = torch.empty((1,), dtype=torch.float32, device=proj.device)
+    check(lib.hvc_resize_loss_fwd(proj.data_ptr(), target.data_ptr(), out.data_ptr(), ws.data_ptr(), B, h, w, S1, S2, tb,
+                                  int(bool(align_corners)), int(mode), _stream()), "hvc_resize_loss_fwd")
+    return out
+
+
+def resize_loss_grad(proj, target, gscale, align_corners, mode):
+    """d loss / d resized image, (B, S1, S2); the adjoint of the resize (trilinear_bwd with depth 1) takes it from there."""
+    _dev(proj, target, gscale)
+    B, h, w = proj.shape
+    S1, S2 = target.shape[1], target.shape[2]
+    tb = target.stride(0) if B > 1 else S1 * S2
+    d = torch.empty((B, S1, S2), dtype=torch.float32, device=proj.device)
+    check(_lib.load().hvc_resize_loss_grad(proj.data_ptr(), target.data_ptr(), _ptr(_f32c(gscale, "gscale")), d.data_ptr(), B, h, w, S1, S2, tb,
+                                           int(bool(align_corners)), int(mode), _stream()), "hvc_resize_loss_grad")
+    return d
+
+
+def view_mean_gap_fwd(feats, V):
+    """feats (B*V, P, E) channels-last feature maps (fp32 / bf16, contiguous) -> mean over views (B, P, E) fp32, pooled (B, E) fp32."""
+    _dev(feats)
+    if feats.dim() != 3 or not feats.is_contiguous() or feats.shape[0] % V:
+        raise ValueError("view_mean_gap: contiguous (B*V, P, E) expected")
+    BV, P, E = feats.shape
+    B = BV // V
+    lib = _lib.load()
+    ws = torch.empty((lib.hvc_view_mean_gap_workspace(B, P, E),), dtype=torch.float32, device=feats.device)
+    mean = torch.empty((B, P, E), dtype=torch.float32, device=feats.device)
+    pooled = torch.empty((B, E), dtype=torch.float32, device=feats.device)
+    check(lib.hvc_view_mean_gap_fwd(feats.data_ptr(), mean.data_ptr(), pooled.data_ptr(), ws.data_ptr(), B, V, P, E, _code(feats.dtype), _stream()),
+          "hvc_view_mean_gap_fwd")
+    return mean, pooled
+
+
+def view_mean_gap_bwd(dmean, dpooled, V, dtype):
+    _dev(dmean, dpooled)
+    ref = dmean if dmean is not None else dpooled
+    if dmean is not None:
+        B, P, E = dmean.shape
+    else:
+        raise ValueError("view_mean_gap_bwd: dmean gives the geometry")
+    df = torch.empty((B * V, P, E), dtype=dtype, device=ref.device)
+    check(_lib.load().hvc_view_mean_gap_bwd(_ptr(_f32c(dmean, "dmean")), _ptr(_f32c(dpooled, "dpooled")), df.data_ptr(), B, V, P, E, _code(dtype),
+                                            _stream()), "hvc_view_mean_gap_bwd")
+    return df

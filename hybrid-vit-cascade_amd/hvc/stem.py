@@ -23,7 +23,9 @@ STAGE_BACKEND = {
     "trilinear_upsample": "hip",
     "xray_conv2d": "hip (im2col + MFMA GEMM)",
     "xray_batchnorm_relu_pool": "hip",
-    "xray_view_mean_gap": "aten",
+    "xray_view_mean_gap": "hip (fused)",
+    "drr_projection_resize_l1_mse": "hip (fused resize + reduction)",
+    "frequency_loss": "rocFFT + hip (fused magnitude / mask / L1)",
     "ssim_l1_loss": "hip",
     "cascade_glue_conv_gn_gelu_upsample": "hip (slab-wise im2col above 2 GiB)",
 }

@@ -49,12 +49,11 @@ class XrayConditioningModule(nn.Module):
     def forward(self, xrays: torch.Tensor, t: torch.Tensor):
         B, V = xrays.shape[0], xrays.shape[1]
         # channels-last feature map (B*V, H', W', E) straight out of the HIP stem
-        if V > 1:
-            f = HS.xray_encoder(self.encoder, xrays.reshape(B * V, *xrays.shape[2:]))
-            f = f.view(B, V, *f.shape[1:]).float().mean(dim=1)             # average the views (reference :126)
-        else:
-            f = HS.xray_encoder(self.encoder, xrays[:, 0]).float()
-        pooled = f.mean(dim=(1, 2))                                        # global average pool (reference :131)
+        # view mean (reference :126) and global average pool (:131) in one fused pass over the stem's output
+        enc = HS.xray_encoder(self.encoder, xrays.reshape(B * V, *xrays.shape[2:]) if V > 1 else xrays[:, 0])
+        hh, ww, E = enc.shape[1:]
+        f, pooled = HF.ViewMeanGapFn.apply(enc.reshape(B * V if V > 1 else B, hh * ww, E), V if V > 1 else 1)
+        f = f.view(B, hh, ww, E)
         feats = f.permute(0, 3, 1, 2)     # (B, E, H', W') view; .flatten(2).transpose(1, 2) of it is copy-free
         f32 = torch.float32
         xray_context = HF.linear(pooled, self.to_cond.weight, self.to_cond.bias, f32, f32)
@@ -73,8 +72,6 @@ class ProjectionLoss(nn.Module):
 
     def forward(self, volume: torch.Tensor, xray_target: torch.Tensor, angle: float = 0) -> torch.Tensor:
         drr = self.drr_renderer(volume.squeeze(1), angle=angle)
-        target = xray_target.squeeze(1)
-        if drr.shape != target.shape:
-            drr = F.interpolate(drr.unsqueeze(1), size=xray_target.shape[2:], mode="bilinear",
-                                align_corners=True).squeeze(1)
-        return F.mse_loss(drr, target)
+        # bilinear (align_corners=True) resize to the X-ray raster + MSE, fused: the resized image is never written
+        # (a same-size "resize" is the identity at align_corners=True, so one path serves both branches of the reference)
+        return HF.ResizeLossFn.apply(drr, xray_target.squeeze(1), True, 1)

@@ -260,6 +260,29 @@ int hvc_spectral_l1_fwd(const float* pred_spec, const float* target_spec, float*
 int hvc_spectral_l1_bwd(const float* pred_spec, const float* target_spec, const float* gscale, float* dpred_spec,
                         int B, int D, int H, int W, void* stream);
 
+/* Projection-loss epilogue: bilinear resize of a projection (B, h, w) fp32 to (S1, S2) fused with the reduction against
+ * the target X-ray (B, S1, S2) (rows contiguous, batch stride target_bstride elements, so a view xrays[:, v] is passed in place):
+ *   mode 0: mean |r - t|     - DRRReprojectionLoss, reference direct_regression/progressive_cascade/loss_multiscale.py:269-293
+ *                              (align_corners = 0)
+ *   mode 1: mean (r - t)^2   - ProjectionLoss, reference models/diagnostic_losses.py:161-169 (align_corners = 1)
+ * fwd writes the scalar out1; the resized image is never materialised.  grad writes dresized = gscale[0] * d out1 / d r
+ * (B, S1, S2); the caller feeds it to hvc_trilinear_bwd with depth 1 (the adjoint of the resize).  workspace:
+ * hvc_resize_loss_workspace floats. */
+int64_t hvc_resize_loss_workspace(int B, int S1, int S2);
+int hvc_resize_loss_fwd(const float* proj, const float* target, float* out1, float* workspace, int B, int h, int w, int S1, int S2,
+                        int64_t target_bstride, int align_corners, int mode, void* stream);
+int hvc_resize_loss_grad(const float* proj, const float* target, const float* gscale, float* dresized, int B, int h, int w,
+                         int S1, int S2, int64_t target_bstride, int align_corners, int mode, void* stream);
+
+/* Mean over the V views of the channels-last X-ray feature maps feats (B*V, P, E) (P = H'*W' positions) fused with the global
+ * average pool over P (reference models/diagnostic_losses.py:126, :131): mean (B, P, E) fp32, pooled (B, E) fp32.
+ * bwd: dfeats[(b, v)] = (dmean[b] + dpooled[b] / P) / V for every view (either gradient may be NULL).
+ * workspace: hvc_view_mean_gap_workspace floats. */
+int64_t hvc_view_mean_gap_workspace(int B, int P, int E);
+int hvc_view_mean_gap_fwd(const void* feats, float* mean, float* pooled, float* workspace, int B, int V, int P, int E, int dtype,
+                          void* stream);
+int hvc_view_mean_gap_bwd(const float* dmean, const float* dpooled, void* dfeats, int B, int V, int P, int E, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1490,13 +1490,20 @@ def test_train_step_vs_reference_fixture(golden, mode):
                 continue                                     # zero-gradient biases ahead of train-mode BN: both sides hold noise
             metric = "l2" if (mode == "bf16" or k.startswith(routed)) else "max"
             g.check(f"step{step}_clipped", k, p.grad, max(tol, 3e-2) if k.startswith(routed) else tol, 10, metric=metric)
-            if step == 1:
-                # step 1 of AdamW is -lr * (sign-like g / (|g| + eps)) - lr * wd * w: insensitive to the size of g, so even the
-                # bf16 run must land on the reference's weights except where a tiny gradient's sign is decided by rounding
-                moved_badly[k] = g.check_step_move("params", "step1_after", k, before[k], p, lr, 0.02 if mode == "f32" else 0.12, 0.25)
-            g.check(f"step{step}_after", k, p, 1e-3 if mode == "f32" else 5e-3)
-        if step == 1:
-            print(f"train_step [{mode}]: worst fraction of weights whose first AdamW move differs: {max(moved_badly.values()):.3%}")
+            # AdamW moves every weight by <= ~lr per step whatever the gradient's size (step 1 is sign-like: -lr g / (|g| + eps)
+            # - lr wd w), so weights are compared by how far they MOVED from the initial fixture weights, in units of lr: even the
+            # bf16 run must land on the reference's weights except where a tiny gradient's sign is decided by rounding
+            # (such a weight ends 2 lr away per step, never more).
+            ref_after, pick = g.ref_values(f"step{step}_after", k)
+            ref_move = ref_after - pick(g.z[f"params/{k}"].astype(np.float64))
+            got_move = pick((p.detach().double().cpu() - torch.from_numpy(g.z[f"params/{k}"]).double()).numpy())
+            diff = np.abs(got_move - ref_move)
+            assert diff.max() <= 2.1 * lr * step, (k, diff.max() / lr)
+            moved_badly[k] = float((diff > 0.3 * lr).mean())
+            # bf16: gradients behind the ReLU / max-pool routing (X-ray stem) are the noisiest, and a sign-like update amplifies it
+            bound = 0.02 if mode == "f32" else (0.30 if k.startswith(routed) else 0.15)
+            assert moved_badly[k] <= bound, (k, moved_badly[k])
+        print(f"train_step [{mode}] step {step}: worst fraction of weights that moved differently (> 0.3 lr): {max(moved_badly.values()):.3%}")
     for k, v in m.state_dict().items():
         if "running_" in k:
             g.check("step2_after", k, v, 10 * tol)
@@ -1549,3 +1556,47 @@ def test_weight_cast_cache_sees_data_assignment_and_device_moves():
     lin.weight.data.mul_(0.5)                                  # in place through .data: invisible to the key ...
     HF.invalidate_param_casts()                                # ... so the documented call is required
     assert torch.allclose(run(), y0, rtol=2e-2, atol=1e-3)
+
+
+@pytest.mark.parametrize("cfg", [(2, 13, 9, 32, 24, False, 0), (1, 64, 64, 128, 128, False, 0), (3, 40, 56, 16, 20, False, 0),
+                                 (2, 13, 9, 32, 24, True, 1), (2, 24, 24, 24, 24, True, 1), (1, 50, 7, 20, 31, True, 1), (2, 8, 8, 8, 8, False, 0)])
+def test_resize_loss_kernels_vs_aten(cfg):
+    """Fused bilinear resize + L1 / MSE (tails of DRRReprojectionLoss and ProjectionLoss) against F.interpolate + loss:
+    value and gradient, both corner conventions, up- and down-sampling, non-square rasters, a strided target view."""
+    import torch.nn.functional as F
+    from hvc import functional as HF
+    B, h, w, S1, S2, ac, mode = cfg
+    g = torch.Generator().manual_seed(B * 1000 + h * 31 + w)
+    proj = torch.randn(B, h, w, generator=g).to(dev()).requires_grad_(True)
+    packed = torch.randn(B, 2, 1, S1, S2, generator=g).to(dev())
+    target = packed[:, 1, 0]                                         # strided view, as the X-ray views are
+    got = HF.ResizeLossFn.apply(proj, target, ac, mode)
+    got.backward()
+    p2 = proj.detach().clone().requires_grad_(True)
+    r = F.interpolate(p2[:, None], size=(S1, S2), mode="bilinear", align_corners=ac)[:, 0]
+    ref = F.mse_loss(r, target) if mode else F.l1_loss(r, target)
+    ref.backward()
+    assert abs(got.item() - ref.item()) < 1e-5 * abs(ref.item()) + 1e-7
+    assert (proj.grad - p2.grad).abs().max().item() < 1e-5 * p2.grad.abs().max().item() + 1e-9
+
+
+@pytest.mark.parametrize("cfg", [(2, 2, 64, 32, torch.float32), (1, 2, 4096, 512, torch.bfloat16), (3, 1, 50, 64, torch.float32),
+                                 (2, 3, 17, 256, torch.bfloat16)])
+def test_view_mean_gap_kernels_vs_aten(cfg):
+    """Fused mean over views + global average pool of the channels-last X-ray feature maps, forward and backward."""
+    from hvc import functional as HF
+    B, V, P, E, dt = cfg
+    g = torch.Generator().manual_seed(P + E)
+    f = torch.randn(B * V, P, E, generator=g).to(dev(), dt).requires_grad_(True)
+    wm = torch.randn(B, P, E, generator=g).to(dev())
+    wp = torch.randn(B, E, generator=g).to(dev())
+    mean, pooled = HF.ViewMeanGapFn.apply(f, V)
+    ((mean * wm).sum() + (pooled * wp).sum()).backward()
+    f2 = f.detach().float().requires_grad_(True)
+    m2 = f2.view(B, V, P, E).mean(1)
+    p2 = m2.mean(1)
+    ((m2 * wm).sum() + (p2 * wp).sum()).backward()
+    assert (mean - m2).abs().max().item() < 1e-5 * m2.abs().max().item()
+    assert (pooled - p2).abs().max().item() < 2e-5 * p2.abs().max().item() + 1e-7
+    tol = 1e-5 if dt == torch.float32 else 1e-2
+    assert (f.grad.float() - f2.grad).abs().max().item() < tol * f2.grad.abs().max().item()
