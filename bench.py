@@ -34,6 +34,7 @@ WORKLOADS = {
     "direct256": dict(volume=(256, 256, 256), batch=1, name="Direct model at 256^3 (north_star's third resolution), bf16, batch=1/GPU"),
 }
 MFMA_BF16_PEAK_TFLOPS = 2500.0     # dense, /opt/skills/guides/MI355X_MICROARCH.md
+ATTN_KERNELS = {"attn_fwd_kernel", "attn_fwd2_kernel", "attn_bwd_dkv_kernel", "attn_bwd_dq_kernel", "attn_delta_kernel"}
 
 
 def fwd_flops_per_volume(model):
@@ -55,13 +56,13 @@ def fwd_flops_per_volume(model):
     return xray + vox + L * block, dict(N=N, M=M, C=C, L=L)
 
 
-def build(workload, device):
+def build(workload, device, capturable=False):
     from direct_regression.model_direct import DirectCTRegression, DirectRegressionLoss
     torch.manual_seed(0)
     model = DirectCTRegression(volume_size=workload["volume"], xray_img_size=512, voxel_dim=256, vit_depth=4,
                                num_heads=4, xray_feature_dim=512).to(device).train()
     crit = DirectRegressionLoss(1.0, 0.5)
-    opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=0.01, fused=True)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=0.01, fused=True, capturable=capturable)
     return model, crit, opt
 
 
@@ -122,6 +123,26 @@ def cpu_baseline(seconds_budget=30.0):
                       f"{cores} threads, best step {best:.2f} s"}
 
 
+def other_resolutions(main_workload):
+    """north_star quotes volumes/s at 64^3, 128^3 and 256^3: short runs of the other two resolutions (child processes of this
+    one, 10 timed steps each), reported beside the headline line."""
+    import subprocess
+    out = {}
+    for wl in ("direct64", "direct128", "direct256"):
+        if wl == main_workload:
+            continue
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", wl, "--steps", "10", "--warmup", "3", "--no-cpu-baseline",
+                            "--no-extra", "--no-profile"], capture_output=True, text=True, timeout=900)
+        line = next((ln for ln in r.stdout.splitlines() if ln.startswith("{")), None)
+        if r.returncode or line is None:
+            out[wl] = {"error": (r.stderr or r.stdout)[-300:]}
+            continue
+        d = json.loads(line)
+        out[wl] = {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "batch_per_gpu": d["config"]["batch_per_gpu"],
+                   "tokens": d["config"]["tokens"], "launch": d["config"]["launch"], "steps": d["steps"]}
+    return out
+
+
 def _free_port():
     import socket
     with socket.socket() as sk:
@@ -148,6 +169,9 @@ def main():
     ap.add_argument("--workload", default="direct128", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip per-kernel HIP-event timing")
+    ap.add_argument("--graph", default="auto", choices=("auto", "on", "off"),
+                    help="replay the step as one captured hipGraph (auto: for the launch-bound direct64 workload, single GPU)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the short 64^3 / 256^3 runs reported under other_resolutions")
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -177,7 +201,10 @@ def main():
 
     from hvc import ops, stem
     wl = WORKLOADS[args.workload]
-    model, crit, opt = build(wl, device)
+    # hipGraph replay of the whole step where the step is launch-bound (64^3: ~300 launches in ~10 ms of kernels); the
+    # 128^3 / 256^3 steps are GPU-bound and run eagerly, which also lets HIP events bracket their kernels in the timed region
+    use_graph = world == 1 and (args.graph == "on" or (args.graph == "auto" and args.workload == "direct64"))
+    model, crit, opt = build(wl, device, capturable=use_graph)
     params = [p for p in model.parameters() if p.requires_grad]
     fwd_flops, geom = fwd_flops_per_volume(model)
     step_model = model
@@ -194,17 +221,25 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    def eager_step():
+        return train_step(step_model, params, crit, opt, xr, ct)
+    step = eager_step
+    if use_graph:
+        from hvc.graph import GraphedStep
+        graphed = GraphedStep(lambda a_, b_: train_step(step_model, params, crit, opt, a_, b_), [xr, ct], warmup=max(args.warmup, 3))
+        step = lambda: graphed(xr, ct)                    # noqa: E731
     for _ in range(args.warmup):
-        train_step(step_model, params, crit, opt, xr, ct)
+        step()
     barrier()
-    # Timed region: K steps.  Only the attention kernels (the dominant-kernel candidates, 32 launches per step) are
-    # bracketed by HIP events here, which perturbs the step by < 1 %; the full per-kernel table comes from an extra,
-    # untimed pass below (bracketing all ~300 launches per step costs 40 % at 64^3, where the step is 15 ms).
-    prof = None if args.no_profile else []
-    ops.PROFILE, ops.PROFILE_ONLY = prof, {"attn_fwd_kernel", "attn_bwd_dkv_kernel", "attn_bwd_dq_kernel", "attn_delta_kernel"}
+    # Timed region: K steps.  Eager mode: only the attention kernels (the dominant-kernel candidates, 32 launches per step)
+    # are bracketed by HIP events here, which perturbs the step by < 1 %; the full per-kernel table comes from an extra,
+    # untimed pass below (bracketing all ~300 launches per step costs 40 % at 64^3).  Graph mode: a replay hides the
+    # individual launches, so both tables come from eager passes after the timed region.
+    prof = None if (args.no_profile or use_graph) else []
+    ops.PROFILE, ops.PROFILE_ONLY = prof, ATTN_KERNELS
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = train_step(step_model, params, crit, opt, xr, ct)
+        loss = step()
     barrier()
     elapsed = time.perf_counter() - t0
     ops.PROFILE, ops.PROFILE_ONLY = None, None
@@ -212,13 +247,23 @@ def main():
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = t.item()
+    roofline_note = f"the {args.steps} timed steps (HIP events on the launch stream)"
+    if use_graph and not args.no_profile:
+        prof = []
+        ops.PROFILE, ops.PROFILE_ONLY = prof, ATTN_KERNELS
+        for _ in range(min(args.steps, 5)):
+            eager_step()
+        torch.cuda.synchronize()
+        ops.PROFILE, ops.PROFILE_ONLY = None, None
+        roofline_note = (f"{min(args.steps, 5)} eager steps after the timed region (HIP events on the launch stream; the timed region "
+                         "replays a hipGraph, which hides individual launches)")
     full = None
     if prof is not None and rank == 0 and world == 1:
         full = []
         ops.PROFILE = full
         extra = min(args.steps, 3)
         for _ in range(extra):
-            train_step(step_model, params, crit, opt, xr, ct)
+            eager_step()
         torch.cuda.synchronize()
         ops.PROFILE = None
 
@@ -236,6 +281,7 @@ def main():
                        "global_batch": wl["batch"] * world, "tokens": geom["N"], "context_tokens": geom["M"],
                        "layers": geom["L"], "parallelism": f"dp{world}", "train_mode_dropout": 0.1,
                        "gradient_checkpointing": False, "optimizer": "AdamW(fused) + clip_grad_norm 1.0",
+                       "launch": "hipGraph replay of the captured step" if use_graph else "eager (one launch per kernel)",
                        "loss": float(loss.item()), "stage_backends": stem.STAGE_BACKEND},
             "algorithmic_tflops_per_volume_fwd_bwd": 3 * fwd_flops / 1e12,
             "achieved_model_tflops_per_gpu": 3 * fwd_flops * wl["batch"] * args.steps / elapsed / 1e12,
@@ -263,8 +309,8 @@ def main():
                                "unit": "TFLOP/s", "frac": work / tsec / 1e12 / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic,
                                "launches": n, "avg_launch_ms": 1e3 * tsec / n,
                                "algorithmic_flops_per_launch": work / n}
-            out["roofline"]["measured_over"] = f"the {args.steps} timed steps (HIP events on the launch stream)"
-            share_src, share_steps = (full, min(args.steps, 3)) if full else (prof, args.steps)
+            out["roofline"]["measured_over"] = roofline_note
+            share_src, share_steps = (full, min(args.steps, 3)) if full else (prof, min(args.steps, 5) if use_graph else args.steps)
             agg2 = {}
             for name, work, s_ev, e_ev in share_src:
                 a = agg2.setdefault(name, [0.0, 0.0, 0])
@@ -282,6 +328,8 @@ def main():
                 out["nccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
             except Exception:       # noqa: BLE001 - informational only
                 out["nccl_version"] = None
+        if world == 1 and not args.no_extra:
+            out["other_resolutions"] = other_resolutions(args.workload)
         if not args.no_cpu_baseline and world == 1:      # host-CPU baseline: rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

@@ -201,7 +201,9 @@ __device__ __forceinline__ void load_row_frags_scaled(const T* rowp, int h, bool
 // forward
 // ---------------------------------------------------------------------------------
 template <typename T, int D, bool DROP, bool VEC>
-__global__ __launch_bounds__(256, sizeof(T) == 2 ? 3 : 2) void attn_fwd_kernel(const AttnArgs a) {
+__global__ __launch_bounds__(256, sizeof(T) == 2 ? 3 : 2) void attn_fwd_kernel(const AttnArgs a_in) {
+    AttnArgs a = a_in;
+    a.seed_lo = seed_with_counter(a_in.seed_lo, a_in.seed_ctr);
     constexpr int NS = NSplit<T>::value;
     constexpr int TILE = kKT * D;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -440,7 +442,9 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 3 : 2) void attn_fwd_kernel(c
 constexpr int kQB2 = 256, kKT2 = 32;
 
 template <int D, bool DROP>
-__global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const AttnArgs a) {
+__global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const AttnArgs a_in) {
+    AttnArgs a = a_in;
+    a.seed_lo = seed_with_counter(a_in.seed_lo, a_in.seed_ctr);
     using T = bf16;
     constexpr int TILE = kKT2 * D;
     constexpr int CPR = D / 8;                         // 16-byte chunks per tile row
@@ -684,7 +688,9 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const AttnArgs a) {
 // backward: dQ
 // ---------------------------------------------------------------------------------
 template <typename T, int D, bool DROP, bool VEC>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a_in) {
+    AttnArgs a = a_in;
+    a.seed_lo = seed_with_counter(a_in.seed_lo, a_in.seed_ctr);
     constexpr int NS = NSplit<T>::value;
     constexpr int TILE = kKT * D;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -864,7 +870,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
 // backward: dK, dV
 // ---------------------------------------------------------------------------------
 template <typename T, int D, bool DROP, bool VEC>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a_in) {
+    AttnArgs a = a_in;
+    a.seed_lo = seed_with_counter(a_in.seed_lo, a_in.seed_ctr);
     constexpr int NS = NSplit<T>::value;
     constexpr int TILE = kKT * D;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1139,11 +1147,20 @@ size_t fwd_lds_bytes() { return (size_t)2 * 2 * NSplit<T>::value * kKT * D * siz
 template <typename T, int D>
 size_t dkv_lds_bytes(bool drop) { return fwd_lds_bytes<T, D>() + 2 * 2 * kKT * sizeof(float) + (drop ? 2 * kKT * kLotStride * sizeof(uint16_t) : 0); }
 
+// Raises a kernel's dynamic-LDS limit once per (kernel, size): the attribute is sticky, and a driver call per launch would
+// also sit inside hipGraph captures of the training step.
 template <typename K>
 hipError_t set_lds(K kernel, size_t bytes) {
-    if (bytes > 48 * 1024)
-        return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    return hipSuccess;
+    if (bytes <= 48 * 1024) return hipSuccess;
+    static thread_local const void* done_fn[64];
+    static thread_local size_t done_bytes[64];
+    static thread_local int ndone = 0;
+    const void* fn = reinterpret_cast<const void*>(kernel);
+    for (int i = 0; i < ndone; ++i)
+        if (done_fn[i] == fn && done_bytes[i] >= bytes) return hipSuccess;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess && ndone < 64) { done_fn[ndone] = fn; done_bytes[ndone] = bytes; ++ndone; }
+    return e;
 }
 
 template <typename T, int D, bool DROP, bool VEC>

@@ -10,6 +10,11 @@
 namespace {
 
 thread_local char g_err[256] = "";
+// Device word every dropout seed is offset by (hvc_set_seed_counter); null = seeds are taken as passed.  Per thread, like the
+// HIP current-device state: one process (and one trainer thread) per GPU.
+thread_local const uint32_t* g_seed_ctr = nullptr;
+
+__global__ void seed_counter_advance_kernel(uint32_t* ctr, uint32_t step) { *ctr += step; }
 
 int fail(int code, const char* msg) {
     snprintf(g_err, sizeof(g_err), "%s", msg);
@@ -37,6 +42,17 @@ extern "C" {
 
 int hvc_abi_version(void) { return HVC_ABI_VERSION; }
 const char* hvc_last_error(void) { return g_err; }
+
+int hvc_set_seed_counter(const uint32_t* device_counter) {
+    g_seed_ctr = device_counter;
+    return 0;
+}
+
+int hvc_seed_counter_advance(uint32_t* device_counter, uint32_t step, void* stream) {
+    if (!device_counter) return fail(HVC_E_BADARG, "seed_counter_advance: null counter");
+    hipLaunchKernelGGL(seed_counter_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, device_counter, step);
+    return hip_result(hipGetLastError(), "seed_counter_advance");
+}
 
 int hvc_device_info(int* cu_count, int* wavefront, char* arch, int arch_len) {
     int dev = 0;
@@ -72,7 +88,7 @@ static int fill_attn(hvc::AttnArgs& a, const void* q, const void* k, const void*
     a.dk_sb = k_sb; a.dk_sn = k_sn; a.dk_sh = k_sh;
     a.dv_sb = v_sb; a.dv_sn = v_sn; a.dv_sh = v_sh;
     a.scale = scale;
-    a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32);
+    a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32); a.seed_ctr = g_seed_ctr;
     a.drop_thresh = drop_threshold(p_drop);
     a.keep_scale = 1.f / (1.f - p_drop);
     a.is_bf16 = dtype == HVC_BF16;
@@ -143,7 +159,7 @@ int hvc_gemm(const void* A, const void* B, void* C, int M, int N, int K,
     g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.a_kmajor = a_kmajor != 0; g.b_kmajor = b_kmajor != 0;
     g.alpha = alpha; g.bias = bias; g.act = act; g.aux = aux; g.zsave = zsave; g.ldz = ldz; g.gate = gate; g.residual = residual; g.ldr = ldr; g.residual_rows = residual_rows > 0 ? residual_rows : 0;
     g.rows_per_batch = rows_per_batch > 0 ? rows_per_batch : M;
-    g.seed_lo = (uint32_t)seed; g.seed_hi = (uint32_t)(seed >> 32);
+    g.seed_lo = (uint32_t)seed; g.seed_hi = (uint32_t)(seed >> 32); g.seed_ctr = g_seed_ctr;
     g.drop_thresh = drop_threshold(p_drop);
     g.keep_scale = 1.f / (1.f - p_drop);
     g.in_bf16 = in_dtype == HVC_BF16; g.out_bf16 = out_dtype == HVC_BF16;
@@ -220,7 +236,7 @@ int hvc_branch_bwd(const float* dy, const void* z, const float* gate, void* dz, 
     a.rows = rows; a.N = N; a.rows_per_batch = rows_per_batch; a.blocks_per_batch = hvc::rowops_blocks(rows_per_batch);
     a.out_bf16 = out_dtype == HVC_BF16;
     if (!(p_drop >= 0.f) || !(p_drop < 1.f)) return fail(HVC_E_BADARG, "branch_bwd: bad p_drop");
-    a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32);
+    a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32); a.seed_ctr = g_seed_ctr;
     a.drop_thresh = drop_threshold(p_drop); a.keep_scale = 1.f / (1.f - p_drop);
     return hip_result(hvc::branch_bwd_launch(a, (hipStream_t)stream), "branch_bwd");
 }

@@ -318,7 +318,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
         }
         if (g.drop_thresh) {      // j is a multiple of 8: two 4-column hash groups per row segment
             bool keep[8];
-            drop2d_keep8(drop2d_rowkey(g.seed_lo, g.seed_hi, (uint64_t)i), (uint32_t)j, g.drop_thresh, keep);
+            drop2d_keep8(drop2d_rowkey(seed_with_counter(g.seed_lo, g.seed_ctr), g.seed_hi, (uint64_t)i), (uint32_t)j, g.drop_thresh, keep);
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = keep[e] ? v[e] * g.keep_scale : 0.f;
         }
@@ -374,9 +374,11 @@ hipError_t launch(const GemmArgs& g_in, hipStream_t st) {
     constexpr int BK = sizeof(TI) == 2 ? 64 : 32;
     const size_t lds = (size_t)2 * 2 * NS * 128 * BK * sizeof(bf16);
     auto k = gemm_kernel<TI, TO, AKM, BKM>;
-    if (lds > 48 * 1024) {
+    static thread_local bool lds_raised = false;      // per instantiation; sticky attribute, set once (also keeps it out of graph captures)
+    if (lds > 48 * 1024 && !lds_raised) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
+        lds_raised = true;
     }
     const int tiles = ((g.M + kBM - 1) / kBM) * ((g.N + kBN - 1) / kBN);
     const int nkt = (g.K + BK - 1) / BK;

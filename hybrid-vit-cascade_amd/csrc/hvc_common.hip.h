@@ -205,6 +205,13 @@ __device__ __forceinline__ bf16x8 tr_frag_at(const bf16* pa, const bf16* pb) {
 // Counter-based dropout RNG shared by forward and backward kernels: keep(...) is a pure function of
 // (seed, element coordinates); 16-bit thresholds.
 // ---------------------------------------------------------------------------------
+// Dropout seeds may carry a device-resident step counter (hvc_set_seed_counter): a captured hipGraph replays the same kernel
+// arguments every step, so the per-step variation of every dropout mask comes from one word in HBM that the graph's first node
+// advances.  Forward and backward of one step read the same value, so they regenerate the same masks.
+__device__ __forceinline__ uint32_t seed_with_counter(uint32_t seed_lo, const uint32_t* ctr) {
+    return ctr ? seed_lo + *ctr * 0x9E3779B9u : seed_lo;
+}
+
 __device__ __forceinline__ uint32_t mix32(uint32_t x) {
     x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
     return x;

@@ -24,6 +24,7 @@ struct AttnArgs {
     int64_t dv_sb, dv_sn, dv_sh;
     float scale;
     uint32_t seed_lo, seed_hi;
+    const uint32_t* seed_ctr;   // device step counter folded into the seed (hvc_set_seed_counter), or null
     uint32_t drop_thresh;   // 0 = no dropout; element dropped when its 16-bit lot < thresh
     float keep_scale;       // 1 / (1 - p)
     int vec;                // 16-byte vector access legal for every operand
@@ -57,6 +58,7 @@ struct GemmArgs {
     int residual_rows;       // > 0: residual has this many rows and is indexed by i % residual_rows (pos_embed broadcast)
     int rows_per_batch;
     uint32_t seed_lo, seed_hi, drop_thresh;
+    const uint32_t* seed_ctr;   // device step counter folded into the seed, or null
     float keep_scale;
     int in_bf16, out_bf16;
     int vec_a, vec_b;
@@ -105,6 +107,7 @@ struct BranchArgs {
     int rows, N, rows_per_batch, blocks_per_batch;
     int out_bf16;
     uint32_t seed_lo, seed_hi, drop_thresh;   // output dropout applied by the forward GEMM epilogue
+    const uint32_t* seed_ctr;   // device step counter folded into the seed, or null
     float keep_scale;
 };
 hipError_t branch_bwd_launch(const BranchArgs& a, hipStream_t st);

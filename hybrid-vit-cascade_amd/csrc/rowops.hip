@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void branch_bwd_kernel(const BranchArgs a) {
                 for (int j = 0; j < 8; ++j) v[j] = d[j] * gt[j];
                 if (a.drop_thresh) {
                     bool keep[8];
-                    drop2d_keep8(drop2d_rowkey(a.seed_lo, a.seed_hi, (uint64_t)bidx * rpb + rr), (uint32_t)(c8 * 8), a.drop_thresh, keep);
+                    drop2d_keep8(drop2d_rowkey(seed_with_counter(a.seed_lo, a.seed_ctr), a.seed_hi, (uint64_t)bidx * rpb + rr), (uint32_t)(c8 * 8), a.drop_thresh, keep);
 #pragma unroll
                     for (int j = 0; j < 8; ++j) v[j] = keep[j] ? v[j] * a.keep_scale : 0.f;
                 }
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void branch_bwd_kernel(const BranchArgs a) {
                 const float d = a.dy[e];
                 float v = d * gt;
                 if (a.drop_thresh)
-                    v = drop2d_keep(drop2d_rowkey(a.seed_lo, a.seed_hi, (uint64_t)bidx * rpb + rr), (uint32_t)c, a.drop_thresh) ? v * a.keep_scale : 0.f;
+                    v = drop2d_keep(drop2d_rowkey(seed_with_counter(a.seed_lo, a.seed_ctr), a.seed_hi, (uint64_t)bidx * rpb + rr), (uint32_t)c, a.drop_thresh) ? v * a.keep_scale : 0.f;
                 if (z) sg += d * to_f<TO>(z[e]);
                 sb += v;
                 dz[e] = from_f<TO>(v);

@@ -20,6 +20,8 @@ _i, _i64, _u64, _f, _p = C.c_int, C.c_int64, C.c_uint64, C.c_float, C.c_void_p
 SIGNATURES = {
     "hvc_abi_version": (_i, []),
     "hvc_last_error": (C.c_char_p, []),
+    "hvc_set_seed_counter": (_i, [_p]),
+    "hvc_seed_counter_advance": (_i, [_p, C.c_uint32, _p]),
     "hvc_device_info": (_i, [C.POINTER(_i), C.POINTER(_i), C.c_char_p, _i]),
     "hvc_attention_fwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i] + [_i64] * 12 + [_f, _f, _u64, _i, _p]),
     "hvc_attention_bwd_workspace": (_i64, [_i, _i, _i, _i, _i]),

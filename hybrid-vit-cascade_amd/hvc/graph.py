@@ -1,0 +1,58 @@
+"""Whole-step hipGraph capture (MI355X: a 64^3 training step is ~300 kernel launches of ~30 us each, i.e. launch-bound on
+the host; replaying one captured graph removes the per-launch host cost).
+
+The step function (forward + loss + backward + clip + optimizer, as direct_regression/train_direct_4gpu.py:62-75 of the
+reference) is captured once on static input buffers.  Dropout masks must still change from step to step although a replayed
+graph passes identical kernel arguments, so every mask-drawing kernel offsets its seed by a device-resident step counter
+(include/hvc_hip.h: hvc_set_seed_counter) that the first node of the graph advances.
+"""
+import torch
+
+from . import _lib
+
+
+class GraphedStep:
+    """graphed = GraphedStep(step_fn, example_inputs); loss = graphed(*inputs) replays the captured step.
+
+    step_fn(*inputs) must be capture-safe: static shapes, no host synchronisation (.item(), printing tensors), optimizer
+    created with capturable=True.  It returns a tensor or a tuple / dict of tensors (e.g. the loss), which stay valid until the
+    next call."""
+
+    def __init__(self, step_fn, example_inputs, warmup=3):
+        if not torch.cuda.is_available():
+            raise RuntimeError("GraphedStep needs the MI355X HIP device")
+        if warmup < 1:
+            # lazily created state (AdamW's moments, cached bf16 weight copies) must exist BEFORE the capture: initialisations
+            # recorded inside the graph would run again on every replay and reset that state
+            raise ValueError("GraphedStep needs at least one eager warm-up step ahead of the capture")
+        self.lib = _lib.load()
+        self.static_inputs = [t.clone() for t in example_inputs]
+        dev = self.static_inputs[0].device
+        self.counter = torch.zeros(1, dtype=torch.int32, device=dev)          # read as uint32 on the device
+        _lib.check(self.lib.hvc_set_seed_counter(self.counter.data_ptr()), "hvc_set_seed_counter")
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self._advance(side)
+                step_fn(*self.static_inputs)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self._advance(torch.cuda.current_stream(dev))
+            self.static_outputs = step_fn(*self.static_inputs)
+
+    def _advance(self, stream):
+        _lib.check(self.lib.hvc_seed_counter_advance(self.counter.data_ptr(), 1, stream.cuda_stream), "hvc_seed_counter_advance")
+
+    def __call__(self, *inputs):
+        for dst, src in zip(self.static_inputs, inputs):
+            if dst.data_ptr() != src.data_ptr():
+                dst.copy_(src, non_blocking=True)
+        self.graph.replay()
+        return self.static_outputs
+
+    def close(self):
+        """Detach the device counter from the library (seeds are taken as passed again)."""
+        _lib.check(self.lib.hvc_set_seed_counter(None), "hvc_set_seed_counter")

@@ -5,6 +5,7 @@ checks its operands, allocates outputs with torch.empty and passes raw device po
 libhvc_hip.so.  Non-HIP tensors are rejected -- there is no fallback path.
 """
 import math
+import os
 
 import torch
 
@@ -93,7 +94,9 @@ def attention_fwd(q, k, v, scale, p_drop=0.0, seed=0):
         raise ValueError("attention: q/k/v shape or dtype mismatch")
     o = torch.empty((B, Nq, H, D), dtype=q.dtype, device=q.device)
     lse = torch.empty((B, H, Nq), dtype=torch.float32, device=q.device)
-    with _Timed("attn_fwd_kernel", 4.0 * B * H * Nq * Nk * D):
+    # the library runs the 64-rows-per-wave kernel from 512 workgroups up (csrc/attention.hip launch_fwd): label the timing so
+    two_blocks = q.dtype == torch.bfloat16 and ((Nq + 255) // 256) * B * H >= 512 and os.environ.get("HVC_ATTN_FWD_ROWS") != "32"
+    with _Timed("attn_fwd2_kernel" if two_blocks or os.environ.get("HVC_ATTN_FWD_ROWS") == "64" else "attn_fwd_kernel", 4.0 * B * H * Nq * Nk * D):
       check(_lib.load().hvc_attention_fwd(
         q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse.data_ptr(), B, H, Nq, Nk, D,
         *_bnhd_strides(q), *_bnhd_strides(k), *_bnhd_strides(v), *_bnhd_strides(o),

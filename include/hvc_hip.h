@@ -39,6 +39,16 @@ extern "C" {
 /* Library / device probes (host side only, no kernel launch). */
 int hvc_abi_version(void);
 const char* hvc_last_error(void);
+/* Device-resident dropout step counter (for hipGraph capture of a training step: a replayed graph passes the same seed
+ * arguments every time, so the per-step variation of every dropout mask must live in device memory).  After
+ * hvc_set_seed_counter(ptr) every kernel that draws dropout masks (attention probabilities, GEMM-epilogue dropouts and their
+ * backward passes) offsets its 64-bit seed argument by the 32-bit word at ptr, read on the device at kernel start; forward and
+ * backward of one step see the same value and so regenerate the same masks.  hvc_seed_counter_advance enqueues a one-thread
+ * kernel adding `step` to the word - captured as the first node of the step's graph.  NULL restores plain seeds.  The
+ * setting is per host thread.  (The reference draws its masks from torch's Philox stream: train_direct_4gpu.py:65-71.) */
+int hvc_set_seed_counter(const uint32_t* device_counter);
+int hvc_seed_counter_advance(uint32_t* device_counter, uint32_t step, void* stream);
+
 /* Fills CU count and wavefront size of the current device and its gcnArchName; 0 on success. */
 int hvc_device_info(int* cu_count, int* wavefront, char* arch, int arch_len);
 
