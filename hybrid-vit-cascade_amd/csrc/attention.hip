@@ -35,10 +35,14 @@ namespace {
 
 constexpr int kKT = 64;     // keys (or queries, in dKV) per LDS tile
 constexpr int kQB = 128;    // rows per workgroup
-// Row stride (in 16-bit lots) of the dK/dV kernel's dropout-lot tile: 128 keys + 8 of padding = 272 bytes, so that
-// the 16 query rows a wavefront writes with ds_write_b128 land on 16 distinct 4-bank groups, and the rows q and q+4
-// read by the two lane halves of a wavefront land on disjoint banks (rocprofv3: SQ_LDS_BANK_CONFLICT 402 M -> 0).
-constexpr int kLotStride = kQB + 8;
+// dK/dV kernel's dropout-lot tile: one row per query of the tile, four 32-key parts (one per wavefront) of 64 bytes each, stored
+// 80 bytes apart, rows 320 bytes apart.  The generator's ds_write_b128 is served in groups of 8 lanes = 2 query rows x 4 parts:
+// part starts of 0 / 80 / 160 / 240 bytes and a row step of 320 bytes (= 16 banks mod 32) put the eight 16-byte stores of a group
+// on eight distinct 4-bank groups.  With the parts contiguous (64-byte steps) parts 0 / 2 and 1 / 3 met on the same banks:
+// rocprofv3 counted SQ_LDS_BANK_CONFLICT = 1 cycle per MFMA (134 M per launch at N = 32768, profiles/r01_pmc_attention_*) for this
+// kernel, all of it from these stores (the fragment reads of the Q / dO tiles are conflict-free, as in the forward and dQ kernels).
+constexpr int kLotPart = 32 + 8;           // 16-bit lots from one part's start to the next (32 keys + 16 bytes)
+constexpr int kLotStride = 4 * kLotPart;   // lots per tile row
 constexpr float kRescaleLog2 = 6.f;   // deferred running-max update: P stays <= 2^6 between rescales
 
 // 8 elements of row n (zeros when n >= nrows).  VEC: one clamped 16-byte load + select (no branch).
@@ -939,7 +943,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a_i
             // keys 128 kb + 32 part + 4 u .. + 3: 64-key tile 2 kb + (part >> 1), group j = 8 (part & 1) + u
             const uint32_t rk0 = drop_rowkey(a, bh, q), tadd = (uint32_t)(2 * kb + (part >> 1)) * kTileAdd;
             const uint32_t rk[2] = {(rk0 + tadd) ^ drop_grp_a(part & 1), ((rk0 ^ kGrpH) + tadd) ^ drop_grp_a(part & 1)};
-            uint32_t* dst = reinterpret_cast<uint32_t*>(lots + ((size_t)buf * kKT + ql) * kLotStride + 32 * part);
+            uint32_t* dst = reinterpret_cast<uint32_t*>(lots + ((size_t)buf * kKT + ql) * kLotStride + kLotPart * part);
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const uint32_t m = rk[u & 1] ^ drop_grp_b(u >> 1);
@@ -964,7 +968,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a_i
     for (int dt = 0; dt < D / 32; ++dt)
 #pragma unroll
         for (int i = 0; i < 16; ++i) { dk[dt][i] = 0.f; dv[dt][i] = 0.f; }
-    const int kcol = wave * 32 + r;          // this lane's key column in the lots tile
 
     // per-lane LDS addresses: Q / dO row fragments share one set, their transposed fragments another; the tile buffer
     // is a compile-time constant of each instantiation of the step (the sweep is unrolled by two).
@@ -980,7 +983,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a_i
         taddr[dt][1] = lds + ob;
     }
     const float* stat_lane = stat + 4 * h;                            // row constants of query rows 4h + {0..3} (+ 8g + 32qt)
-    const uint16_t* lots_lane = lots + 4 * h * kLotStride + kcol;
+    const uint16_t* lots_lane = lots + 4 * h * kLotStride + wave * kLotPart + r;
 
     auto step = [&](auto buf_tag, int t) {
         constexpr int buf = decltype(buf_tag)::value;
