@@ -113,6 +113,26 @@ int hvc_attention_fwd(const void* q, const void* k, const void* v, void* o, floa
     return hip_result(hvc::attention_launch(a, false, (hipStream_t)stream), "attention_fwd");
 }
 
+int64_t hvc_attention_fwd_fp8_workspace(int B, int H, int Nk, int D) {
+    if (B < 1 || H < 1 || Nk < 1 || (D != 32 && D != 64)) return -1;
+    return hvc::attention_fp8_workspace_bytes(B, H, Nk, D);
+}
+
+int hvc_attention_fwd_fp8(const void* q, const void* k, const void* v, void* o, float* lse, void* workspace,
+                          int B, int H, int Nq, int Nk, int D,
+                          int64_t q_sb, int64_t q_sn, int64_t q_sh, int64_t k_sb, int64_t k_sn, int64_t k_sh,
+                          int64_t v_sb, int64_t v_sn, int64_t v_sh, int64_t o_sb, int64_t o_sn, int64_t o_sh,
+                          float scale, float p_drop, uint64_t seed, void* stream) {
+    hvc::AttnArgs a;
+    int rc = fill_attn(a, q, k, v, B, H, Nq, Nk, D, q_sb, q_sn, q_sh, k_sb, k_sn, k_sh, v_sb, v_sn, v_sh, o_sb, o_sn, o_sh, scale, p_drop, seed, HVC_BF16);
+    if (rc) return rc;
+    if (!o || !lse || !workspace) return fail(HVC_E_BADARG, "attention_fwd_fp8: null output / workspace");
+    if (!a.vec || !aligned16(q) || !aligned16(k) || !aligned16(v) || !aligned16(o) || !aligned16(workspace))
+        return fail(HVC_E_UNSUPPORTED, "attention_fwd_fp8: operands must be bf16 with 16-byte addressable rows (strides multiples of 8)");
+    a.o = o; a.lse = lse;
+    return hip_result(hvc::attention_fp8_launch(a, workspace, (hipStream_t)stream), "attention_fwd_fp8");
+}
+
 int64_t hvc_attention_bwd_workspace(int B, int H, int Nq, int Nk, int D) {
     if (B < 1 || H < 1 || Nq < 1 || Nk < 1 || D < 1) return -1;
     const int qs = hvc::attention_bwd_qsplit(B, H, Nq, Nk);

@@ -36,6 +36,8 @@ struct AttnArgs {
 };
 hipError_t attention_launch(const AttnArgs& a, bool bwd, hipStream_t st);
 int attention_bwd_qsplit(int B, int H, int Nq, int Nk);
+int64_t attention_fp8_workspace_bytes(int B, int H, int Nk, int D);
+hipError_t attention_fp8_launch(const AttnArgs& a, void* workspace, hipStream_t st);      // forward, fp8 (e4m3) MFMA products
 
 enum GemmAct { kActNone = 0, kActGelu = 1, kActGeluGrad = 2 };
 

@@ -33,6 +33,7 @@ for _p in (_PKG, os.path.join(_PKG, "direct_regression")):
     if _p not in sys.path:
         sys.path.insert(0, _p)
 
+from hvc import functional as HF
 from hvc import stem  # noqa: E402
 from progressive_cascade.model_progressive import ProgressiveCascadeModel  # noqa: E402
 from progressive_cascade.loss_multiscale import MultiScaleLoss, compute_psnr, compute_ssim_metric  # noqa: E402
@@ -177,6 +178,8 @@ def train_stage(rank, world_size, config, stage, checkpoint_dir, synthetic=False
     if rank == 0:
         print(f"\n{'=' * 60}\nTraining Stage {stage}\n{'=' * 60}\n")
     device = torch.device("cuda", rank % max(torch.cuda.device_count(), 1))
+    # "mi355x": {"fp8_attention": true} runs the attention forward's Q K^T / P V products as fp8 (e4m3) MFMAs (BASELINE configs[4])
+    HF.set_fp8_attention(bool(config.get("mi355x", {}).get("fp8_attention", False)))
     model, criterion, optimizer, scheduler = build_stage(config, stage, checkpoint_dir, device, rank)
     ddp_model = wrap_ddp(model, [device.index]) if dist.is_initialized() else model
     scaler = torch.amp.GradScaler("cuda", enabled=False)      # bf16: no loss scaling; object kept for API parity

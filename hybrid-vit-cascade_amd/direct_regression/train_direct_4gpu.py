@@ -28,6 +28,7 @@ if _PKG not in sys.path:
     sys.path.insert(0, _PKG)
 
 from direct_regression.model_direct import DirectCTRegression, DirectRegressionLoss  # noqa: E402
+from hvc import functional as HF  # noqa: E402
 from utils.dataset import PatientDRRDataset  # noqa: E402
 
 BUCKET_CAP_MB = 32
@@ -148,6 +149,7 @@ def train_ddp(rank, world_size, config, resume_from=None, synthetic=False):
         setup_ddp(rank, world_size)
     if rank == 0:
         print("\n" + "=" * 80 + "\nDIRECT CT REGRESSION (NO DIFFUSION) - MI355X data-parallel training\n" + "=" * 80)
+    HF.set_fp8_attention(bool(config.get("mi355x", {}).get("fp8_attention", False)))      # opt-in fp8 (e4m3) attention products
     model = DirectCTRegression(**config["model"]).cuda(rank)
     if rank == 0:
         total = sum(p.numel() for p in model.parameters())

@@ -24,6 +24,8 @@ SIGNATURES = {
     "hvc_seed_counter_advance": (_i, [_p, C.c_uint32, _p]),
     "hvc_device_info": (_i, [C.POINTER(_i), C.POINTER(_i), C.c_char_p, _i]),
     "hvc_attention_fwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i] + [_i64] * 12 + [_f, _f, _u64, _i, _p]),
+    "hvc_attention_fwd_fp8_workspace": (_i64, [_i, _i, _i, _i]),
+    "hvc_attention_fwd_fp8": (_i, [_p] * 6 + [_i] * 5 + [_i64] * 12 + [_f, _f, _u64, _p]),
     "hvc_attention_bwd_workspace": (_i64, [_i, _i, _i, _i, _i]),
     "hvc_attention_bwd": (_i, [_p] * 10 + [_i] * 5 + [_i64] * 12 + [_f, _f, _u64, _i, _i, _p]),
     "hvc_gemm": (_i, [_p, _p, _p, _i, _i, _i, _i64, _i64, _i64, _i, _i, _f, _p, _i, _p, _p, _i64, _p, _p, _i64, _i, _i,

@@ -15,6 +15,19 @@ from . import ops
 
 _warned_fp16 = False
 
+# fp8 (e4m3) MFMA products in the attention forward (BASELINE configs[4]); off by default, switched by the trainers from the
+# "mi355x": {"fp8_attention": true} section of the JSON config, or by hand.  Applies to bf16 (autocast) runs only.
+ATTN_FP8 = False
+
+
+def set_fp8_attention(on: bool) -> None:
+    global ATTN_FP8
+    ATTN_FP8 = bool(on)
+
+
+def _fp8(t) -> bool:
+    return ATTN_FP8 and t.dtype == torch.bfloat16
+
 
 def compute_dtype(ref: torch.Tensor) -> torch.dtype:
     """bf16 inside torch.autocast('cuda'), else fp32."""
@@ -208,7 +221,7 @@ class PackedSelfAttnFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, qkv, scale, p_drop, seed):
         q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
-        o, lse = ops.attention_fwd(q, k, v, scale, p_drop, seed)
+        o, lse = ops.attention_fwd(q, k, v, scale, p_drop, seed, fp8=_fp8(q))
         ctx.save_for_backward(qkv, o, lse)
         ctx.cfg = (scale, p_drop, seed)
         B, N, H, D = o.shape
@@ -229,7 +242,7 @@ class PackedCrossAttnFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, q, kv, scale, p_drop, seed):
-        o, lse = ops.attention_fwd(q, kv[:, :, 0], kv[:, :, 1], scale, p_drop, seed)
+        o, lse = ops.attention_fwd(q, kv[:, :, 0], kv[:, :, 1], scale, p_drop, seed, fp8=_fp8(q))
         ctx.save_for_backward(q, kv, o, lse)
         ctx.cfg = (scale, p_drop, seed)
         B, N, H, D = o.shape
@@ -264,7 +277,7 @@ class SelfAttnBranchFn(torch.autograd.Function):
         sc, sh, gt = _mod2d(scale, B, Cn), _mod2d(shift, B, Cn), _mod2d(gate, B, Cn)
         h, mean, rstd = ops.layernorm_fwd(x2, _f32(gamma), _f32(beta), sc, sh, rows_per_batch=N, out_dtype=cdt)
         qkv = ops.gemm(h, cast_param(w_qkv, cdt)).view(B, N, 3, heads, D)
-        o, lse = ops.attention_fwd(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], D ** -0.5, p_drop, seeds[0])
+        o, lse = ops.attention_fwd(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], D ** -0.5, p_drop, seeds[0], fp8=_fp8(qkv))
         o2 = o.view(B * N, Cn)
         z = torch.empty((B * N, Cn), dtype=cdt, device=x.device) if gt is not None else None
         out = ops.gemm(o2, cast_param(w_proj, cdt), bias=_f32(b_proj), zsave=z, gate=gt, residual=x2, rows_per_batch=N,
@@ -308,7 +321,7 @@ class CrossAttnBranchFn(torch.autograd.Function):
         h, mean, rstd = ops.layernorm_fwd(x2, _f32(gamma), _f32(beta), rows_per_batch=N, out_dtype=cdt)
         q = ops.gemm(h, cast_param(w_q, cdt)).view(B, N, heads, D)
         kv = ops.gemm(c2, cast_param(w_kv, cdt)).view(B, M, 2, heads, D)
-        o, lse = ops.attention_fwd(q, kv[:, :, 0], kv[:, :, 1], D ** -0.5, p_drop, seeds[0])
+        o, lse = ops.attention_fwd(q, kv[:, :, 0], kv[:, :, 1], D ** -0.5, p_drop, seeds[0], fp8=_fp8(q))
         out = ops.gemm(o.view(B * N, Cn), cast_param(w_proj, cdt), bias=_f32(b_proj), residual=x2,
                        p_drop=p_drop, seed=seeds[1], out_dtype=torch.float32)
         ctx.save_for_backward(x2, c2, gamma, beta, w_q, w_kv, w_proj, h, mean, rstd, q, kv, o, lse)

@@ -85,8 +85,9 @@ def _bnhd_strides(t):
     return t.stride(0), t.stride(1), t.stride(2)
 
 
-def attention_fwd(q, k, v, scale, p_drop=0.0, seed=0):
-    """q: (B,Nq,H,D), k/v: (B,Nk,H,D) views (any batch/token/head strides). Returns o (B,Nq,H,D), lse (B,H,Nq)."""
+def attention_fwd(q, k, v, scale, p_drop=0.0, seed=0, fp8=False):
+    """q: (B,Nq,H,D), k/v: (B,Nk,H,D) views (any batch/token/head strides). Returns o (B,Nq,H,D), lse (B,H,Nq).
+    fp8=True runs the Q K^T and P V products as fp8 (e4m3) MFMAs (bf16 operands only; hvc_attention_fwd_fp8)."""
     _dev(q, k, v)
     B, Nq, H, D = q.shape
     Nk = k.shape[1]
@@ -94,6 +95,17 @@ def attention_fwd(q, k, v, scale, p_drop=0.0, seed=0):
         raise ValueError("attention: q/k/v shape or dtype mismatch")
     o = torch.empty((B, Nq, H, D), dtype=q.dtype, device=q.device)
     lse = torch.empty((B, H, Nq), dtype=torch.float32, device=q.device)
+    if fp8:
+        if q.dtype != torch.bfloat16:
+            raise TypeError("fp8 attention takes bfloat16 operands (run it under torch.autocast)")
+        lib = _lib.load()
+        ws = torch.empty((lib.hvc_attention_fwd_fp8_workspace(B, H, Nk, D),), dtype=torch.uint8, device=q.device)
+        with _Timed("attn_fwd_fp8_kernel", 4.0 * B * H * Nq * Nk * D):
+            check(lib.hvc_attention_fwd_fp8(
+                q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse.data_ptr(), ws.data_ptr(), B, H, Nq, Nk, D,
+                *_bnhd_strides(q), *_bnhd_strides(k), *_bnhd_strides(v), *_bnhd_strides(o),
+                float(scale), float(p_drop), int(seed), _stream()), "hvc_attention_fwd_fp8")
+        return o, lse
     # the library runs the 64-rows-per-wave kernel from 512 workgroups up (csrc/attention.hip launch_fwd): label the timing so
     two_blocks = q.dtype == torch.bfloat16 and ((Nq + 255) // 256) * B * H >= 512 and os.environ.get("HVC_ATTN_FWD_ROWS") != "32"
     with _Timed("attn_fwd2_kernel" if two_blocks or os.environ.get("HVC_ATTN_FWD_ROWS") == "64" else "attn_fwd_kernel", 4.0 * B * H * Nq * Nk * D):

@@ -71,6 +71,19 @@ int hvc_attention_fwd(const void* q, const void* k, const void* v, void* o, floa
                       int64_t o_sb, int64_t o_sn, int64_t o_sh,
                       float scale, float p_drop, uint64_t seed, int dtype, void* stream);
 
+/* Forward with fp8 (OCP e4m3) MFMA products - v_mfma_f32_32x32x16_fp8_fp8 for Q K^T and P V - the "fp8 MFMA attention" of
+ * BASELINE configs[4] (cascade stage 3: direct_regression/progressive_cascade/model_progressive.py:219-316 runs these
+ * attention modules at 8 heads x 32).  Same contract as hvc_attention_fwd for bf16 operands with 16-byte addressable rows;
+ * softmax statistics, dropout lots and the outputs (bf16 o, fp32 lse) are those of the bf16 kernel, K / V / P are rounded to
+ * e4m3 (3 mantissa bits: stated tolerance 6e-2 relative Frobenius error on o for white-noise operands, 5e-2 on structured ones).  The backward pass is hvc_attention_bwd (bf16)
+ * with this forward's o / lse.  workspace: hvc_attention_fwd_fp8_workspace BYTES (fp8 images of K and of V transposed). */
+int64_t hvc_attention_fwd_fp8_workspace(int B, int H, int Nk, int D);
+int hvc_attention_fwd_fp8(const void* q, const void* k, const void* v, void* o, float* lse, void* workspace,
+                          int B, int H, int Nq, int Nk, int D,
+                          int64_t q_sb, int64_t q_sn, int64_t q_sh, int64_t k_sb, int64_t k_sn, int64_t k_sh,
+                          int64_t v_sb, int64_t v_sn, int64_t v_sh, int64_t o_sb, int64_t o_sn, int64_t o_sh,
+                          float scale, float p_drop, uint64_t seed, void* stream);
+
 /* Floats of scratch hvc_attention_bwd needs: B*H*Nq for delta, plus fp32 partial dK/dV slabs when few key blocks
  * (cross-attention) make the dK/dV kernel slice the query range over extra workgroups. */
 int64_t hvc_attention_bwd_workspace(int B, int H, int Nq, int Nk, int D);
