@@ -210,8 +210,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 3 : 2) void attn_fwd_kernel(c
         for (int i = 0; i < 16; ++i) o[dt][i] = 0.f;
 
     const uint32_t rowkey = DROP ? drop_rowkey(a, bh, qrow_c) ^ (h ? kGrpH : 0u) : 0u;      // lane half = low bit of the group index
-    const DropTs dts = drop_ts(a);
-    const uint32_t tm1x2a = DROP ? drop_tm1x2(dts.lo, dts.hia) : 0u, tm1x2b = DROP ? drop_tm1x2(dts.lo, dts.hib) : 0u;
+    const uint32_t tm1x2 = DROP ? ((uint32_t)(drop_ts(a) - 1) & 0xffffu) * 0x10001u : 0u;
 
     // Per-lane LDS addresses of the K row fragments (one per 16-wide d step) and the transposed V fragments (two row
     // groups per 32-wide d block); tile buffer, key sub-tile and split image enter as immediate offsets.
@@ -313,7 +312,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 3 : 2) void attn_fwd_kernel(c
                         const uint32_t m = rk_tile ^ (drop_grp_a(kt) ^ drop_grp_b(2 * s2 + g2));
                         uint32_t la, lb;
                         drop_lots4(m, la, lb);
-                        const uint32_t ma = drop_keepmask2(la, tm1x2a), mb = drop_keepmask2(lb, tm1x2b);
+                        const uint32_t ma = drop_keepmask2(la, tm1x2), mb = drop_keepmask2(lb, tm1x2);
 #pragma unroll
                         for (int sa = 0; sa < NS; ++sa) {
                             u32x4 w = __builtin_bit_cast(u32x4, pf[sa]);
@@ -425,8 +424,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const AttnArgs a_in) 
         load_row_frags_scaled<T, 1, D / 16, true>(qp + (int64_t)qc * a.q_sn, h, true, sl2, qf[blk]);
         rowkey[blk] = DROP ? drop_rowkey(a, bh, qc) ^ (h ? kGrpH : 0u) : 0u;
     }
-    const DropTs dts = drop_ts(a);
-    const uint32_t tm1x2a = DROP ? drop_tm1x2(dts.lo, dts.hia) : 0u, tm1x2b = DROP ? drop_tm1x2(dts.lo, dts.hib) : 0u;
+    const uint32_t tm1x2 = DROP ? ((uint32_t)(drop_ts(a) - 1) & 0xffffu) * 0x10001u : 0u;
 
     // tile loader: one 16-byte chunk of K and of V per thread (D = 32: the first 128 threads)
     const int lrow = tid / CPR, lch = tid % CPR;
@@ -561,7 +559,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const AttnArgs a_in) 
                         const uint32_t m = rk_tile ^ (drop_grp_a(buf) ^ drop_grp_b(2 * s2 + g2));
                         uint32_t la, lb;
                         drop_lots4(m, la, lb);
-                        const uint32_t ma = drop_keepmask2(la, tm1x2a), mb = drop_keepmask2(lb, tm1x2b);
+                        const uint32_t ma = drop_keepmask2(la, tm1x2), mb = drop_keepmask2(lb, tm1x2);
                         u32x4 w = __builtin_bit_cast(u32x4, pf[0]);
                         w[2 * g2] &= ma;
                         w[2 * g2 + 1] &= mb;
@@ -697,7 +695,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a_in
 #pragma unroll
         for (int i = 0; i < 16; ++i) dq[dt][i] = 0.f;
     const uint32_t rowkey = DROP ? drop_rowkey(a, bh, qrow_c) ^ (h ? kGrpH : 0u) : 0u;      // lane half = low bit of the group index
-    const DropTs ts = drop_ts(a);
+    const int ts = drop_ts(a);
 
     // per-lane LDS addresses (see the forward kernel): K / V row fragments share one set, K^T fragments another
     const bf16* raddr[D / 16];
@@ -912,9 +910,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a_i
     gen_lots(t_begin, t_begin & 1);
     __syncthreads();
 
-    // this lane's key is lot (key & 3) of its 4-key group: the low lots share one threshold, the two high lots have their own
-    const DropTs dts = drop_ts(a);
-    const int ts = (r & 3) == 1 ? dts.hia : ((r & 3) == 3 ? dts.hib : dts.lo);
+    const int ts = drop_ts(a);
     f32x16 dk[D / 32], dv[D / 32];
 #pragma unroll
     for (int dt = 0; dt < D / 32; ++dt)

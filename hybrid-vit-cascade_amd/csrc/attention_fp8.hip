@@ -153,7 +153,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_fp8_kernel(const AttnArgs a_i
 #pragma unroll
         for (int i = 0; i < 16; ++i) o[dt][i] = 0.f;
     const uint32_t rowkey = DROP ? drop_rowkey(a, bh, qrow_c) ^ (h ? kGrpH : 0u) : 0u;
-    const DropTs ts = drop_ts(a);
+    const int ts = drop_ts(a);
 
     for (int t = 0; t < nt; ++t) {
         const int buf = t & 1;
