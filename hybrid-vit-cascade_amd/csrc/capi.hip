@@ -335,6 +335,53 @@ int hvc_im2col(const void* src, void* col, int B, int C, int SD, int SH, int SW,
     return hip_result(hvc::im2col_launch(g, src, col, dtype == HVC_BF16, (hipStream_t)stream), "im2col");
 }
 
+int hvc_conv_gemm(int mode, const void* src, const void* other, void* out, int B, int C, int SD, int SH, int SW,
+                  int KD, int KH, int KW, int stride, int PD, int PH, int PW, int flip, int N, int64_t ld_other, int64_t ld_out,
+                  const float* bias, const float* residual, int64_t ldr, int residual_rows,
+                  float* workspace, int64_t workspace_floats, int in_dtype, int out_dtype, void* stream) {
+    hvc::ConvGeom cgeo;
+    const int64_t K64 = (int64_t)KD * KH * KW * C;
+    int rc = fill_geom(cgeo, B, C, SD, SH, SW, KD, KH, KW, stride, PD, PH, PW, 0, (K64 + 7) / 8 * 8);
+    if (rc) return rc;
+    if (mode != 0 && mode != 1) return fail(HVC_E_BADARG, "conv_gemm: mode must be 0 (patches x weights) or 1 (dy^T x patches)");
+    if (!src || !other || !out || N < 1) return fail(HVC_E_BADARG, "conv_gemm: null operand");
+    if (!dtype_ok(in_dtype) || !dtype_ok(out_dtype)) return fail(HVC_E_BADARG, "conv_gemm: bad dtype");
+    if (in_dtype == HVC_F32 && out_dtype == HVC_BF16) return fail(HVC_E_UNSUPPORTED, "conv_gemm: f32 in / bf16 out not supported");
+    if (C % 8) return fail(HVC_E_UNSUPPORTED, "conv_gemm: the implicit patch gather needs C % 8 == 0 (use im2col + gemm)");
+    if (!aligned16(src)) return fail(HVC_E_BADARG, "conv_gemm: src must be 16-byte aligned");
+    if (cgeo.M >= (1ll << 31) || K64 >= (1ll << 31)) return fail(HVC_E_UNSUPPORTED, "conv_gemm: more than 2^31 patch rows / columns");
+    if (mode == 1 && (bias || residual)) return fail(HVC_E_BADARG, "conv_gemm: the weight-gradient form has no epilogue operands");
+    if (mode == 1 && out_dtype != HVC_F32) return fail(HVC_E_BADARG, "conv_gemm: weight gradients are fp32");
+    hvc::GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    hvc::ConvGather& cg = g.cg;
+    cg.src = src; cg.C = C; cg.SD = SD; cg.SH = SH; cg.SW = SW; cg.KD = KD; cg.KH = KH; cg.KW = KW; cg.stride = stride;
+    cg.PD = PD; cg.PH = PH; cg.PW = PW; cg.flip = flip != 0; cg.M = cgeo.M; cg.K = (int)K64;
+    cg.dC = hvc::make_fastdiv((uint32_t)C); cg.dKW = hvc::make_fastdiv((uint32_t)KW); cg.dKH = hvc::make_fastdiv((uint32_t)KH);
+    cg.dOW = hvc::make_fastdiv((uint32_t)cgeo.OW); cg.dOH = hvc::make_fastdiv((uint32_t)cgeo.OH); cg.dOD = hvc::make_fastdiv((uint32_t)cgeo.OD);
+    g.C = out; g.ldc = ld_out; g.alpha = 1.f; g.act = 0;
+    g.in_bf16 = in_dtype == HVC_BF16; g.out_bf16 = out_dtype == HVC_BF16;
+    g.workspace = workspace; g.workspace_floats = workspace ? workspace_floats : 0;
+    if (mode == 0) {            // out[M][N] = patches[M][K] . other[N][K]^T
+        g.gather = 1;
+        g.A = src; g.lda = K64; g.B = other; g.ldb = ld_other;
+        g.M = (int)cgeo.M; g.N = N; g.K = (int)K64;
+        g.bias = bias; g.residual = residual; g.ldr = ldr; g.residual_rows = residual_rows > 0 ? residual_rows : 0;
+        g.rows_per_batch = g.M;
+        g.vec_a = 1; g.vec_b = aligned16(other) && (ld_other % 8 == 0);
+    } else {                    // out[N][K] = other[M][N]^T . patches[M][K]
+        g.gather = 2;
+        g.a_kmajor = g.b_kmajor = 1;
+        g.A = other; g.lda = ld_other; g.B = src; g.ldb = K64;
+        g.M = N; g.N = (int)K64; g.K = (int)cgeo.M;
+        g.rows_per_batch = g.M;
+        g.vec_a = aligned16(other) && (ld_other % 8 == 0); g.vec_b = 1;
+    }
+    g.vec_epi = (g.N % 8 == 0) && aligned16(out) && (ld_out % 8 == 0) && (!residual || (aligned16(residual) && ldr % 8 == 0)) &&
+                (!workspace || aligned16(workspace));
+    return hip_result(hvc::gemm_launch(g, (hipStream_t)stream), "conv_gemm");
+}
+
 int hvc_col2im(const void* dcol, void* dsrc, int B, int C, int SD, int SH, int SW, int KD, int KH, int KW, int stride,
                int PD, int PH, int PW, int OD, int64_t Kp, int dtype, void* stream) {
     hvc::ConvGeom g;

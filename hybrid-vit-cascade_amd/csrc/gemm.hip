@@ -122,12 +122,94 @@ struct OperandTile {
     }
 };
 
-template <typename TI, typename TO, bool AKM, bool BKM>
+__device__ __forceinline__ uint32_t fdiv(uint32_t n, const FastDiv& f) { return (__umulhi(n, f.m) + n) >> f.l; }
+
+// Operand tile whose elements are convolution patches gathered from a channels-last activation tensor (implicit GEMM:
+// the patch matrix of spatial.hip's im2col never exists in HBM).  Same LDS image and fragments as OperandTile.
+//   KM = false: tile rows = patch rows m (output positions), chunk = 8 channels of one tap.  A thread keeps the decoded
+//               positions of its CPT rows for the whole k loop and decodes its (tap, channel) once per k-tile.
+//   KM = true : tile rows = contraction index = patch rows m, columns = patch columns.  A thread's (tap, channel) is
+//               fixed for the whole kernel; its CPT patch rows are decoded per k-tile.
+template <typename T, int BK, bool KM>
+struct GatherTile : OperandTile<T, BK, KM> {
+    using Base = OperandTile<T, BK, KM>;
+    static constexpr int CPT = Base::CPT, CPR = Base::CPR;
+    int pd[CPT], ph[CPT], pw[CPT], pb[CPT];    // KM = false: per-row first source coordinate (o * stride - pad), b * SD
+    int kd, kh, kw, kc;                         // KM = true : this thread's tap and first channel (kd < 0: beyond K)
+
+    static __device__ __forceinline__ void taps_of(const ConvGather& cg, int k, int& d, int& h, int& w, int& c) {
+        const uint32_t tap = fdiv((uint32_t)k, cg.dC);
+        c = k - (int)tap * cg.C;
+        const uint32_t t2 = fdiv(tap, cg.dKW);
+        w = (int)(tap - t2 * cg.KW);
+        const uint32_t t3 = fdiv(t2, cg.dKH);
+        h = (int)(t2 - t3 * cg.KH);
+        d = (int)t3;
+        if (cg.flip) { d = cg.KD - 1 - d; h = cg.KH - 1 - h; w = cg.KW - 1 - w; }
+    }
+    static __device__ __forceinline__ void rows_of(const ConvGather& cg, int64_t m, int& d0, int& h0, int& w0, int& b0) {
+        if (m >= cg.M) { d0 = h0 = w0 = -(1 << 24); b0 = 0; return; }     // fails every bounds test
+        const uint32_t q1 = fdiv((uint32_t)m, cg.dOW);
+        const uint32_t ow = (uint32_t)m - q1 * cg.dOW.d;
+        const uint32_t q2 = fdiv(q1, cg.dOH);
+        const uint32_t oh = q1 - q2 * cg.dOH.d;
+        const uint32_t b = fdiv(q2, cg.dOD);
+        const uint32_t od = q2 - b * cg.dOD.d;
+        d0 = (int)od * cg.stride - cg.PD;
+        h0 = (int)oh * cg.stride - cg.PH;
+        w0 = (int)ow * cg.stride - cg.PW;
+        b0 = (int)b * cg.SD;
+    }
+    static __device__ __forceinline__ Chunk8<T> fetch(const ConvGather& cg, int b0, int sd, int sh, int sw, int c) {
+        const bool ok = (unsigned)sd < (unsigned)cg.SD && (unsigned)sh < (unsigned)cg.SH && (unsigned)sw < (unsigned)cg.SW;
+        if (!ok) return zero_chunk<T>();
+        const int64_t pos = ((int64_t)(b0 + sd) * cg.SH + sh) * cg.SW + sw;
+        return load_chunk<T>(reinterpret_cast<const T*>(cg.src) + pos * cg.C + c, 8, true);
+    }
+
+    // x0: first tile row (KM = false: patch row i0;  KM = true: patch column j0)
+    __device__ __forceinline__ void init(const ConvGather& cg, int x0, int tid) {
+        if constexpr (!KM) {
+#pragma unroll
+            for (int c = 0; c < CPT; ++c) rows_of(cg, (int64_t)x0 + (tid + 256 * c) / CPR, pd[c], ph[c], pw[c], pb[c]);
+        } else {
+            const int k = x0 + (tid % CPR) * 8;
+            kd = -1;
+            if (k < cg.K) taps_of(cg, k, kd, kh, kw, kc);
+        }
+    }
+    // k0: first contraction index of the tile (KM = false: patch column;  KM = true: patch row)
+    template <int SET>
+    __device__ __forceinline__ void issue(const ConvGather& cg, int64_t k0, int tid) {
+        if constexpr (!KM) {
+            const int k = (int)k0 + (tid % CPR) * 8;
+            if (k < cg.K) {
+                int d, h, w, cc;
+                taps_of(cg, k, d, h, w, cc);
+#pragma unroll
+                for (int c = 0; c < CPT; ++c) this->reg[SET][c] = fetch(cg, pb[c], pd[c] + d, ph[c] + h, pw[c] + w, cc);
+            } else {
+#pragma unroll
+                for (int c = 0; c < CPT; ++c) this->reg[SET][c] = zero_chunk<T>();
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < CPT; ++c) {
+                int d0, h0, w0, b0;
+                rows_of(cg, k0 + (tid + 256 * c) / CPR, d0, h0, w0, b0);
+                this->reg[SET][c] = kd < 0 ? zero_chunk<T>() : fetch(cg, b0, d0 + kd, h0 + kh, w0 + kw, kc);
+            }
+        }
+    }
+};
+
+template <typename TI, typename TO, bool AKM, bool BKM, int GATHER>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
     constexpr int NS = NSplit<TI>::value;
     constexpr int BK = sizeof(TI) == 2 ? 64 : 32;
-    using TA = OperandTile<TI, BK, AKM>;
-    using TB = OperandTile<TI, BK, BKM>;
+    static_assert(GATHER == 0 || (GATHER == 1 && !AKM && !BKM) || (GATHER == 2 && AKM && BKM), "gather variants: forward / dW layouts only");
+    using TA = std::conditional_t<GATHER == 1, GatherTile<TI, BK, false>, OperandTile<TI, BK, AKM>>;
+    using TB = std::conditional_t<GATHER == 2, GatherTile<TI, BK, true>, OperandTile<TI, BK, BKM>>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16* lds = reinterpret_cast<bf16*>(smem);
     constexpr int A_SZ = NS * TA::IMG, B_SZ = NS * TB::IMG;
@@ -171,13 +253,27 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
     // Software pipeline, two k-tiles deep: while tile kt is multiplied out of LDS buffer kt & 1, tile kt+1 sits in one
     // register set (written to the other LDS buffer at the end of the step) and tile kt+2 is in flight into the other
     // set - a load has two compute phases to arrive, which matters at the blocks' K = 256 (4 tiles).
-    ta.init(Ap, g.lda, i0, kt_begin * BK, tid);
-    tb.init(Bp, g.ldb, j0, kt_begin * BK, tid);
-    ta.template issue<0>(Ap, g.lda, i0, g.M, kt_begin * BK, g.K, g.vec_a != 0, tid);
-    tb.template issue<0>(Bp, g.ldb, j0, g.N, kt_begin * BK, g.K, g.vec_b != 0, tid);
+    auto issue_a = [&](auto set_tag, int kt) {
+        constexpr int set = decltype(set_tag)::value;
+        if constexpr (GATHER == 1) ta.template issue<set>(g.cg, (int64_t)kt * BK, tid);
+        else ta.template issue<set>(Ap, g.lda, i0, g.M, kt * BK, g.K, g.vec_a != 0, tid);
+    };
+    auto issue_b = [&](auto set_tag, int kt) {
+        constexpr int set = decltype(set_tag)::value;
+        if constexpr (GATHER == 2) tb.template issue<set>(g.cg, (int64_t)kt * BK, tid);
+        else tb.template issue<set>(Bp, g.ldb, j0, g.N, kt * BK, g.K, g.vec_b != 0, tid);
+    };
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    if constexpr (GATHER == 1) ta.init(g.cg, i0, tid);
+    else ta.init(Ap, g.lda, i0, kt_begin * BK, tid);
+    if constexpr (GATHER == 2) tb.init(g.cg, j0, tid);
+    else tb.init(Bp, g.ldb, j0, kt_begin * BK, tid);
+    issue_a(S0{}, kt_begin);
+    issue_b(S0{}, kt_begin);
     if (kt_begin + 1 < kt_end) {
-        ta.template issue<1>(Ap, g.lda, i0, g.M, (kt_begin + 1) * BK, g.K, g.vec_a != 0, tid);
-        tb.template issue<1>(Bp, g.ldb, j0, g.N, (kt_begin + 1) * BK, g.K, g.vec_b != 0, tid);
+        issue_a(S1{}, kt_begin + 1);
+        issue_b(S1{}, kt_begin + 1);
     }
     ta.template commit<0>(At(0), tid);
     tb.template commit<0>(Bt(0), tid);
@@ -195,8 +291,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
     auto kstep = [&](auto buf_tag, int kt) {
         constexpr int buf = decltype(buf_tag)::value;
         if (kt + 2 < kt_end) {
-            ta.template issue<buf>(Ap, g.lda, i0, g.M, (kt + 2) * BK, g.K, g.vec_a != 0, tid);
-            tb.template issue<buf>(Bp, g.ldb, j0, g.N, (kt + 2) * BK, g.K, g.vec_b != 0, tid);
+            issue_a(buf_tag, kt + 2);
+            issue_b(buf_tag, kt + 2);
         }
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
@@ -225,14 +321,12 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
         __syncthreads();
     };
     {
-        using B0 = std::integral_constant<int, 0>;
-        using B1 = std::integral_constant<int, 1>;
         int kt = kt_begin;
         for (; kt + 1 < kt_end; kt += 2) {
-            kstep(B0{}, kt);
-            kstep(B1{}, kt + 1);
+            kstep(S0{}, kt);
+            kstep(S1{}, kt + 1);
         }
-        if (kt < kt_end) kstep(B0{}, kt);
+        if (kt < kt_end) kstep(S0{}, kt);
     }
 
     // ---- epilogue: stage the 128 x 128 fp32 tile through LDS (the operand buffers are free now) so that
@@ -367,13 +461,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs g) {
     }
 }
 
-template <typename TI, typename TO, bool AKM, bool BKM>
+template <typename TI, typename TO, bool AKM, bool BKM, int GATHER = 0>
 hipError_t launch(const GemmArgs& g_in, hipStream_t st) {
     GemmArgs g = g_in;
     constexpr int NS = NSplit<TI>::value;
     constexpr int BK = sizeof(TI) == 2 ? 64 : 32;
     const size_t lds = (size_t)2 * 2 * NS * 128 * BK * sizeof(bf16);
-    auto k = gemm_kernel<TI, TO, AKM, BKM>;
+    auto k = gemm_kernel<TI, TO, AKM, BKM, GATHER>;
     static thread_local bool lds_raised = false;      // per instantiation; sticky attribute, set once (also keeps it out of graph captures)
     if (lds > 48 * 1024 && !lds_raised) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -410,6 +504,8 @@ hipError_t launch(const GemmArgs& g_in, hipStream_t st) {
 
 template <typename TI, typename TO>
 hipError_t launch_layout(const GemmArgs& g, hipStream_t st) {
+    if (g.gather == 1) return (g.a_kmajor || g.b_kmajor) ? hipErrorInvalidValue : launch<TI, TO, false, false, 1>(g, st);
+    if (g.gather == 2) return (!g.a_kmajor || !g.b_kmajor) ? hipErrorInvalidValue : launch<TI, TO, true, true, 2>(g, st);
     if (g.a_kmajor) return g.b_kmajor ? launch<TI, TO, true, true>(g, st) : launch<TI, TO, true, false>(g, st);
     return g.b_kmajor ? launch<TI, TO, false, true>(g, st) : launch<TI, TO, false, false>(g, st);
 }
@@ -461,7 +557,7 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(const GemmArgs g) {
 hipError_t gemm_launch(const GemmArgs& g, hipStream_t st) {
     if (g.in_bf16) return g.out_bf16 ? launch_layout<bf16, bf16>(g, st) : launch_layout<bf16, float>(g, st);
     if (g.out_bf16) return hipErrorInvalidValue;
-    const bool plain_rows = g.M <= 8 && !g.a_kmajor && !g.b_kmajor && g.act == kActNone && !g.aux && !g.zsave && !g.gate && !g.residual &&
+    const bool plain_rows = g.M <= 8 && !g.gather && !g.a_kmajor && !g.b_kmajor && g.act == kActNone && !g.aux && !g.zsave && !g.gate && !g.residual &&
                             !g.drop_thresh && (g.K % 4 == 0) && (g.lda % 4 == 0) && (g.ldb % 4 == 0) &&
                             (reinterpret_cast<uintptr_t>(g.A) & 15) == 0 && (reinterpret_cast<uintptr_t>(g.B) & 15) == 0;
     if (plain_rows) {

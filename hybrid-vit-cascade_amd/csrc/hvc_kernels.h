@@ -41,6 +41,30 @@ hipError_t attention_fp8_launch(const AttnArgs& a, void* workspace, hipStream_t 
 
 enum GemmAct { kActNone = 0, kActGelu = 1, kActGeluGrad = 2 };
 
+// Division by a launch-time constant for operands below 2^31 (Granlund-Montgomery round-up form):
+// n / d == (mulhi(n, m) + n) >> l  with l = ceil(log2 d), m = floor(2^32 (2^l - d) / d) + 1.
+struct FastDiv { uint32_t d, m, l; };
+inline FastDiv make_fastdiv(uint32_t d) {
+    FastDiv f;
+    f.d = d;
+    f.l = 0;
+    while ((1ull << f.l) < d) ++f.l;
+    f.m = (uint32_t)((((1ull << f.l) - d) << 32) / d + 1);
+    return f;
+}
+
+// Patch gather of a convolution on channels-last activations, evaluated inside the GEMM operand loader instead of
+// being written out by im2col (patch row m = output position, patch column k = tap * C + c, C % 8 == 0).
+struct ConvGather {
+    const void* src;        // [B][SD][SH][SW][C]
+    int C, SD, SH, SW;
+    int KD, KH, KW, stride, PD, PH, PW;
+    int flip;               // taps run backwards (the stride-1 input gradient gathers dy with the mirrored kernel)
+    int64_t M;              // B * OD * OH * OW patch rows
+    int K;                  // KD * KH * KW * C patch columns
+    FastDiv dC, dKW, dKH, dOW, dOH, dOD;
+};
+
 struct GemmArgs {
     const void* A;   // M x K   (k-contiguous: A[i*lda + k];  k-major: A[k*lda + i])
     const void* B;   // N x K   (k-contiguous: B[j*ldb + k];  k-major: B[k*ldb + j])
@@ -68,6 +92,9 @@ struct GemmArgs {
     float* workspace;        // optional split-K scratch (fp32), workspace_floats long
     int64_t workspace_floats;
     int splitk;              // filled in by the launcher
+    int gather;              // 0: both operands in memory; 1: A = conv patches (k-contiguous view), A / lda unused;
+                             // 2: B = conv patches (k-major view: contraction over patch rows), B / ldb unused
+    ConvGather cg;
 };
 int64_t gemm_workspace_floats(int M, int N, int K);
 hipError_t gemm_launch(const GemmArgs& g, hipStream_t st);

@@ -83,6 +83,17 @@ def _conv_w2d_fill(dst, w):
     dst[:, :taps * cin].view(cout, taps, cin).copy_(w.detach().reshape(cout, cin, taps).permute(0, 2, 1))
 
 
+def _conv_w2dT_fill(dst, w):
+    """dst (Cin, taps*Cout) <- w (Cout, Cin, *k) with column = tap * Cout + co: the operand of the stride-1 input gradient
+    taken as an implicit GEMM over dy (ops.conv_gemm with flip=True mirrors the taps in the gather, not here)."""
+    cout, cin = w.shape[0], w.shape[1]
+    taps = w[0, 0].numel()
+    dst.view(cin, taps, cout).copy_(w.detach().reshape(cout, cin, taps).permute(1, 2, 0))
+
+
+_CONV_FILL = {"_hvc_w2d": _conv_w2d_fill, "_hvc_w2dT": _conv_w2dT_fill}
+
+
 def _after_optimizer_step(optimizer, args, kwargs):
     """Refresh every live cached copy from its (just updated) parameter: plain casts in ONE multi-tensor copy, conv layouts
     by one strided cast each; entries whose parameter moved (device / storage) or vanished are dropped and rebuilt lazily."""
@@ -100,7 +111,8 @@ def _after_optimizer_step(optimizer, args, kwargs):
             srcs.append(p.detach())
             dsts.append(dst)
         else:
-            _conv_w2d_fill(dst, p)
+            with torch.no_grad():
+                _CONV_FILL[attr](dst, p)
         rekey.append((p, attr, old_key, dst))
     if dsts:
         with torch.no_grad():
@@ -442,6 +454,24 @@ def conv_weight_2d(weight: torch.Tensor, dtype: torch.dtype, Kp: int) -> torch.T
     return w2
 
 
+def conv_weight_2d_t(weight: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    """(Cout, Cin, *k) parameter -> (Cin, taps*Cout) operand of the implicit-GEMM input gradient; cached like conv_weight_2d."""
+    key = _cache_key(weight, dtype)
+    hit = getattr(weight, "_hvc_w2dT", None)
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    wt = torch.empty((weight.shape[1], weight[0, 0].numel() * weight.shape[0]), dtype=dtype, device=weight.device)
+    with torch.no_grad():
+        _conv_w2dT_fill(wt, weight)
+    try:
+        weight._hvc_w2dT = (key, wt)
+        _register(weight, "_hvc_w2dT")
+    except AttributeError:
+        pass
+    return wt
+
+
+CONV_IMPLICIT = True          # C % 8 == 0 convolutions gather their patches inside the GEMM (no im2col / col2im round trip)
 CONV_SLAB_BYTES = 2 << 30     # patch matrices larger than this are built (and rebuilt in backward) slab by slab along D
 
 
@@ -461,6 +491,32 @@ def _out_slab_geom(geom, od0, od1):
     return lo, hi, g
 
 
+def _conv_dx_slabs(dy5, w2d, geom, cdt):
+    """Input gradient as dcol = dy W (GEMM) -> col2im, in depth slabs when the dcol matrix would exceed CONV_SLAB_BYTES."""
+    cout = dy5.shape[-1]
+    esize = 2 if cdt == torch.bfloat16 else 4
+    if geom.M * geom.Kp * esize <= CONV_SLAB_BYTES and not geom.out_depth:
+        return ops.col2im(ops.gemm(dy5.view(geom.M, cout), w2d, b_kmajor=True), geom)
+    s, p, K = geom.stride, geom.pad[0], geom.kernel[0]
+    dx = torch.empty((geom.B, *geom.src, geom.C), dtype=cdt, device=dy5.device)
+    # input slab [d0, d1) gathers from output depths [od_lo, od_hi); slab size chosen on the dcol matrix
+    step_in = max(1, _slab_plan(geom, esize, CONV_SLAB_BYTES) * s)
+    for b in range(geom.B):
+        for d0 in range(0, geom.src[0], step_in):
+            d1 = min(geom.src[0], d0 + step_in)
+            od_lo = max(0, -((-(d0 + p - K + 1)) // s))
+            od_hi = min(geom.out[0], (d1 - 1 + p) // s + 1)
+            if od_hi <= od_lo:
+                dx[b, d0:d1].zero_()
+                continue
+            g = ops.ConvGeometry(1, geom.C, (d1 - d0, geom.src[1], geom.src[2]), geom.kernel, s,
+                                 (p + d0 - od_lo * s, geom.pad[1], geom.pad[2]), out_depth=od_hi - od_lo)
+            dcol = ops.gemm(dy5[b, od_lo:od_hi].view(g.M, cout), w2d, b_kmajor=True)
+            dx[b, d0:d1] = ops.col2im(dcol, g)[0]
+            del dcol
+    return dx
+
+
 class ConvFn(torch.autograd.Function):
     """Convolution on channels-last x (B, D, H, W, Cin) as im2col + MFMA GEMM (+ bias, + broadcast add of
     `addvec` (N_tok, Cout), i.e. pos_embed, on the last stem layer).  Output (B, OD, OH, OW, Cout).
@@ -473,13 +529,20 @@ class ConvFn(torch.autograd.Function):
         w2d = conv_weight_2d(weight, cdt, geom.Kp)
         cout = weight.shape[0]
         esize = 2 if cdt == torch.bfloat16 else 4
-        slabbed = geom.M * geom.Kp * esize > CONV_SLAB_BYTES
+        implicit = CONV_IMPLICIT and geom.C % 8 == 0 and not geom.out_depth
+        slabbed = not implicit and geom.M * geom.Kp * esize > CONV_SLAB_BYTES
         add = None
         if addvec is not None:
             if slabbed:
                 raise RuntimeError("ConvFn: the fused pos_embed add is only supported for un-slabbed (token-sized) outputs")
             add = _f32(addvec).reshape(-1, cout)
-        if not slabbed:
+        if implicit:
+            xc = xc.contiguous()
+            y = ops.conv_gemm(xc, w2d, geom, bias=_f32(bias), residual=add, residual_rows=add.shape[0] if add is not None else 0,
+                              out_dtype=out_dtype)
+            ctx.save_for_backward(xc, weight)
+            y = y.view(geom.B, *geom.out, cout)
+        elif not slabbed:
             col = ops.im2col(xc, geom)
             y = ops.gemm(col, w2d, bias=_f32(bias), residual=add, residual_rows=add.shape[0] if add is not None else 0,
                          out_dtype=out_dtype)
@@ -497,20 +560,33 @@ class ConvFn(torch.autograd.Function):
                     ops.gemm(col, w2d, bias=bf, out_dtype=out_dtype, out=y[b, od0:od1].view(g.M, cout))
                     del col
             ctx.save_for_backward(xc, weight)
-        ctx.cfg = (geom, cdt, x.dtype, bias is not None, None if addvec is None else tuple(addvec.shape), slabbed)
+        ctx.cfg = (geom, cdt, x.dtype, bias is not None, None if addvec is None else tuple(addvec.shape), slabbed, implicit)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         saved, weight = ctx.saved_tensors
-        geom, cdt, xdt, has_bias, add_shape, slabbed = ctx.cfg
+        geom, cdt, xdt, has_bias, add_shape, slabbed, implicit = ctx.cfg
         cout = weight.shape[0]
         taps = geom.taps
         dyc = _as_cdt(dy.reshape(geom.M, cout), cdt)
         db = ops.colsum(dyc) if has_bias and ctx.needs_input_grad[2] else None
         w2d = conv_weight_2d(weight, cdt, geom.Kp)
         dw = dx = None
-        if not slabbed:
+        if implicit:
+            xc = saved
+            if ctx.needs_input_grad[1]:
+                dw2d = ops.conv_gemm_dw(xc, dyc, geom)                                                   # (Cout, taps*C)
+            if ctx.needs_input_grad[0]:
+                if geom.stride == 1 and cout % 8 == 0:
+                    # dx as an implicit GEMM over dy with the mirrored kernel: no dcol matrix, no col2im
+                    gd = ops.ConvGeometry(geom.B, cout, geom.out, geom.kernel, 1, tuple(k - 1 - p for k, p in zip(geom.kernel, geom.pad)))
+                    assert gd.out == geom.src
+                    dx = ops.conv_gemm(dyc.view(geom.B, *geom.out, cout), conv_weight_2d_t(weight, cdt), gd, flip=True)
+                    dx = dx.view(geom.B, *geom.src, geom.C)
+                else:
+                    dx = _conv_dx_slabs(dyc.view(geom.B, *geom.out, cout), w2d, geom, cdt)
+        elif not slabbed:
             col = saved
             if ctx.needs_input_grad[1]:
                 dw2d = ops.gemm(dyc, col, a_kmajor=True, b_kmajor=True, out_dtype=torch.float32)        # (Cout, Kp)
@@ -520,7 +596,6 @@ class ConvFn(torch.autograd.Function):
             xc = saved
             esize = 2 if cdt == torch.bfloat16 else 4
             dy5 = dyc.view(geom.B, *geom.out, cout)
-            s, p, K = geom.stride, geom.pad[0], geom.kernel[0]
             if ctx.needs_input_grad[1]:
                 dw2d = torch.zeros((cout, geom.Kp), dtype=torch.float32, device=dy.device)
                 step = _slab_plan(geom, esize, CONV_SLAB_BYTES)
@@ -532,22 +607,7 @@ class ConvFn(torch.autograd.Function):
                         dw2d += ops.gemm(dy5[b, od0:od1].view(g.M, cout), col, a_kmajor=True, b_kmajor=True, out_dtype=torch.float32)
                         del col
             if ctx.needs_input_grad[0]:
-                dx = torch.empty((geom.B, *geom.src, geom.C), dtype=cdt, device=dy.device)
-                # input slab [d0, d1) gathers from output depths [od_lo, od_hi); slab size chosen on the dcol matrix
-                step_in = max(1, _slab_plan(geom, esize, CONV_SLAB_BYTES) * s)
-                for b in range(geom.B):
-                    for d0 in range(0, geom.src[0], step_in):
-                        d1 = min(geom.src[0], d0 + step_in)
-                        od_lo = max(0, -((-(d0 + p - K + 1)) // s))
-                        od_hi = min(geom.out[0], (d1 - 1 + p) // s + 1)
-                        if od_hi <= od_lo:
-                            dx[b, d0:d1].zero_()
-                            continue
-                        g = ops.ConvGeometry(1, geom.C, (d1 - d0, geom.src[1], geom.src[2]), geom.kernel, s,
-                                             (p + d0 - od_lo * s, geom.pad[1], geom.pad[2]), out_depth=od_hi - od_lo)
-                        dcol = ops.gemm(dy5[b, od_lo:od_hi].view(g.M, cout), w2d, b_kmajor=True)
-                        dx[b, d0:d1] = ops.col2im(dcol, g)[0]
-                        del dcol
+                dx = _conv_dx_slabs(dy5, w2d, geom, cdt)
         if ctx.needs_input_grad[1]:
             dw = dw2d[:, :taps * geom.C].reshape(cout, taps, geom.C).permute(0, 2, 1).reshape(weight.shape)
         if dx is not None and dx.dtype != xdt:

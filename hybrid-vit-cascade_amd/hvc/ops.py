@@ -378,6 +378,58 @@ def col2im(dcol, geom):
     return dx
 
 
+def _conv_gemm_call(mode, src, other, out, geom, flip, n, bias, residual, residual_rows, ws, ws_n, flops):
+    with _Timed("gemm_kernel", flops):
+        check(_lib.load().hvc_conv_gemm(
+            mode, src.data_ptr(), other.data_ptr(), out.data_ptr(), geom.B, geom.C, *geom.src, *geom.kernel, geom.stride, *geom.pad,
+            int(flip), int(n), _ld(other), _ld(out), _ptr(bias), _ptr(residual), _ld(residual) if residual is not None else 0,
+            int(residual_rows), _ptr(ws), int(ws_n), _code(src.dtype), _code(out.dtype), _stream()), "hvc_conv_gemm")
+    return out
+
+
+def conv_gemm(x, w2d, geom, *, flip=False, bias=None, residual=None, residual_rows=0, out_dtype=None, out=None):
+    """Implicit-GEMM convolution: y[M][N] = patches(x)[M][taps*C] . w2d[N][taps*C]^T (+ bias, + residual rows) without a
+    patch matrix in HBM.  x: channels-last (B, D, H, W, C) contiguous, C % 8 == 0.  With flip=True the taps are
+    mirrored (the stride-1 input gradient: x = dy, w2d = W^T[Cin][taps*Cout], geom built on dy with pads K-1-P)."""
+    _dev(x, w2d, bias, residual, out)
+    if geom.out_depth:
+        raise ValueError("conv_gemm: depth-slab geometries are not needed here (no patch matrix to bound)")
+    if not x.is_contiguous() or x.shape != (geom.B, *geom.src, geom.C) or geom.C % 8:
+        raise ValueError("conv_gemm: contiguous channels-last (B,D,H,W,C) tensor with C % 8 == 0 expected")
+    K = geom.taps * geom.C
+    if w2d.dim() != 2 or w2d.shape[1] != K or not _unit_inner(w2d) or w2d.dtype != x.dtype:
+        raise ValueError("conv_gemm: weights must be (N, taps*C) in the activation dtype")
+    N = w2d.shape[0]
+    out_dtype = out_dtype or x.dtype
+    if out is None:
+        out = torch.empty((geom.M, N), dtype=out_dtype, device=x.device)
+    elif out.shape != (geom.M, N) or not _unit_inner(out) or out.dtype != out_dtype:
+        raise ValueError("conv_gemm: bad out tensor")
+    _f32c(bias, "bias")
+    if residual is not None and (residual.dtype != torch.float32 or residual.shape != (residual_rows or geom.M, N) or not _unit_inner(residual)):
+        raise ValueError("conv_gemm: residual must be fp32 (M,N) (or (residual_rows,N))")
+    return _conv_gemm_call(0, x, w2d, out, geom, flip, N, bias, residual, residual_rows, None, 0, 2.0 * geom.M * N * K)
+
+
+def conv_gemm_dw(x, dy2d, geom):
+    """Weight gradient of the implicit-GEMM convolution: (Cout, taps*C) fp32 = dy2d[M][Cout]^T . patches(x)[M][taps*C]."""
+    _dev(x, dy2d)
+    if geom.out_depth:
+        raise ValueError("conv_gemm_dw: depth-slab geometries are not supported")
+    if not x.is_contiguous() or x.shape != (geom.B, *geom.src, geom.C) or geom.C % 8:
+        raise ValueError("conv_gemm_dw: contiguous channels-last (B,D,H,W,C) tensor with C % 8 == 0 expected")
+    if dy2d.dim() != 2 or dy2d.shape[0] != geom.M or not _unit_inner(dy2d) or dy2d.dtype != x.dtype:
+        raise ValueError("conv_gemm_dw: dy must be (M, Cout) in the activation dtype")
+    K = geom.taps * geom.C
+    N = dy2d.shape[1]
+    out = torch.empty((N, K), dtype=torch.float32, device=x.device)
+    lib = _lib.load()
+    ws, ws_n = None, lib.hvc_gemm_workspace(N, K, geom.M)
+    if ws_n > 0:
+        ws = torch.empty((ws_n,), dtype=torch.float32, device=x.device)
+    return _conv_gemm_call(1, x, dy2d, out, geom, False, N, None, None, 0, ws, max(ws_n, 0), 2.0 * geom.M * N * K)
+
+
 def trilinear_fwd(x, size, align_corners=True):
     """x: (B, d, h, w) fp32 contiguous -> (B, D, H, W)."""
     _dev(x)

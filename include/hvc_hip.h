@@ -210,6 +210,22 @@ int hvc_im2col(const void* src, void* col, int B, int C, int SD, int SH, int SW,
 int hvc_col2im(const void* dcol, void* dsrc, int B, int C, int SD, int SH, int SW, int KD, int KH, int KW,
                int stride, int PD, int PH, int PW, int OD, int64_t Kp, int dtype, void* stream);
 
+/* Convolution as an IMPLICIT GEMM (C % 8 == 0): the patch matrix above is never written; the GEMM's operand loader
+ * gathers the 16-byte channel vectors of each tap straight from the channels-last activations (zero outside the volume).
+ * Replaces the same nn.Conv3d / nn.Conv2d layers (models/hybrid_vit_backbone.py:195-210, models/diagnostic_losses.py:87,92,
+ * direct_regression/progressive_cascade/model_progressive.py:46-49,121-123) without the HBM round trip of col / dcol:
+ *   mode 0: out[M][N]  = patches(src)[M][K] . other[N][K]^T (+ bias[N], + residual rows as in hvc_gemm)
+ *           forward:  src = x, other = W2d[Cout][taps*C], N = Cout
+ *           stride-1 input gradient: src = dy (C = Cout), other = W^T[Cin][taps*Cout] with the taps mirrored
+ *           (flip = 1: tap (kd,kh,kw) of the gather is (KD-1-kd, ...) of the column index), pads K-1-P, N = Cin
+ *   mode 1: out[N][K]  = other[M][N]^T . patches(src)[M][K]   (weight gradient, fp32, deterministic split-K;
+ *           other = dy[M][Cout], N = Cout)
+ * M = B*OD*OH*OW, K = taps*C, O = (S + 2P - K)/stride + 1; M, K < 2^31. */
+int hvc_conv_gemm(int mode, const void* src, const void* other, void* out, int B, int C, int SD, int SH, int SW,
+                  int KD, int KH, int KW, int stride, int PD, int PH, int PW, int flip, int N, int64_t ld_other,
+                  int64_t ld_out, const float* bias, const float* residual, int64_t ldr, int residual_rows,
+                  float* workspace, int64_t workspace_floats, int in_dtype, int out_dtype, void* stream);
+
 /* Trilinear resize of single-channel fp32 volumes [B][d][h][w] -> [B][D][H][W] and its adjoint:
  * align_corners=1 for F.interpolate at models/hybrid_vit_backbone.py:272; align_corners=0 for the cascade's
  * nn.Upsample / F.interpolate (direct_regression/progressive_cascade/model_progressive.py:170,211,239,294). */

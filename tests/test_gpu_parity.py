@@ -1067,11 +1067,22 @@ def test_ddp_two_ranks_on_the_hip_path(tmp_path):
         assert torch.equal(r0["params"][k], r1["params"][k]), k
 
 
+@pytest.fixture(params=["implicit", "im2col"])
+def conv_path(request):
+    """Runs a convolution test on both data paths: patches gathered inside the GEMM (C % 8 == 0) and im2col + GEMM + col2im."""
+    from hvc import functional as HF
+    old = HF.CONV_IMPLICIT
+    HF.CONV_IMPLICIT = request.param == "implicit"
+    yield request.param
+    HF.CONV_IMPLICIT = old
+
+
 @pytest.mark.parametrize("cfg", [(3, 2, 16, 24, 3, 1, 1, (10, 9, 8)), (3, 1, 8, 16, 3, 2, 1, (13, 8, 8)), (3, 2, 1, 8, 3, 2, 1, (12, 6, 6)),
                                  (3, 1, 32, 8, 1, 1, 0, (9, 4, 4))])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_conv_slabbed_equals_whole_and_oracle(cfg, dtype):
-    """Convolution run slab by slab along D (large-volume path) == the single-shot path == F.conv3d of the oracle."""
+def test_conv_slabbed_equals_whole_and_oracle(cfg, dtype, conv_path):
+    """Convolution run slab by slab along D (large-volume path) == the single-shot path == F.conv3d of the oracle.
+    (On the implicit path only the few-channel layers and the strided input gradients still have a matrix to slab.)"""
     import torch.nn.functional as F
     from hvc import functional as HF
     from hvc import ops
@@ -1109,8 +1120,8 @@ def test_conv_slabbed_equals_whole_and_oracle(cfg, dtype):
 
 
 @pytest.mark.parametrize("seed", range(10))
-def test_conv_layers_random_geometry(seed):
-    """nn.Conv2d / nn.Conv3d through hvc.stem.conv_channels_last (im2col + MFMA GEMM, col2im, split-K wgrad) against ATen on
+def test_conv_layers_random_geometry(seed, conv_path):
+    """nn.Conv2d / nn.Conv3d through hvc.stem.conv_channels_last (implicit GEMM, or im2col + MFMA GEMM, col2im; split-K wgrad) against ATen on
     random geometry: kernel 1 / 3 / 5 / 7, stride 1 / 2, asymmetric extents, channel counts on both im2col paths (C % 8 == 0 and
     few-channel), fp32 and bf16 - the stems of diagnostic_losses.py:82-96, hybrid_vit_backbone.py:195-210 and
     model_progressive.py:259-267 (incl. its 1x1x1 convolution)."""
@@ -1157,6 +1168,59 @@ def test_conv_layers_random_geometry(seed):
     assert got_y.shape == yr.shape and rel(got_y, yr.detach()) < tol
     assert rel(got_dx, xr.grad) < tol
     assert rel(layer.weight.grad.cpu(), ref_layer.weight.grad) < tol and rel(layer.bias.grad.cpu(), ref_layer.bias.grad) < tol
+
+
+@pytest.mark.parametrize("cfg", [
+    # is3d, B, Cin, Cout, k, stride, pad, spatial
+    (True, 2, 64, 32, 3, 1, 1, (20, 18, 22)),      # the cascade's detail-enhancer layer shape (model_progressive.py:122), many row tiles
+    (True, 1, 32, 64, 3, 1, 1, (17, 33, 9)),
+    (True, 2, 96, 192, 3, 2, 1, (16, 16, 16)),     # stride-2 stem layer (hybrid_vit_backbone.py:195-210): dx stays on col2im
+    (True, 1, 8, 40, 5, 1, 2, (11, 12, 13)),       # K = 1000: ragged last k-tile, N not a multiple of 8 on the dx side
+    (False, 3, 64, 128, 3, 1, 1, (40, 36)),        # X-ray stem layer (diagnostic_losses.py:87)
+    (False, 2, 128, 256, 3, 1, 1, (21, 19)),
+    (True, 1, 16, 8, 1, 1, 0, (9, 10, 11)),        # 1x1x1
+])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_conv_implicit_gemm_vs_fp64_and_im2col(cfg, dtype):
+    """Implicit-GEMM convolution (hvc_conv_gemm: forward, stride-1 input gradient over dy with mirrored taps, split-K weight
+    gradient) against F.conv in fp64 and against the im2col path: the forward is bit-identical to im2col + GEMM (same
+    products in the same order), the gradients agree to the operand precision."""
+    import torch.nn.functional as F
+    from hvc import functional as HF
+    from hvc import ops
+    is3d, B, Cin, Cout, k, stride, pad, sp = cfg
+    g = torch.Generator().manual_seed(Cin * 131 + Cout + k)
+    x = torch.randn(B, Cin, *sp, generator=g)
+    w = torch.randn(Cout, Cin, *([k] * len(sp)), generator=g) / (Cin * k ** len(sp)) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    xr, wr, br = (t.to(dtype).double().requires_grad_(True) for t in (x, w, b))
+    y_ref = (F.conv3d if is3d else F.conv2d)(xr, wr, br, stride=stride, padding=pad)
+    dy = torch.randn(y_ref.shape, generator=g)
+    y_ref.backward(dy.to(dtype).double())
+    sp3 = tuple(sp) if is3d else (1, *sp)
+    geom = ops.ConvGeometry(B, Cin, sp3, (k,) * 3 if is3d else (1, k, k), stride, (pad,) * 3 if is3d else (0, pad, pad))
+    to_cl = lambda t: (t if is3d else t.unsqueeze(2)).permute(0, 2, 3, 4, 1).contiguous()
+    from_cl = lambda t: (lambda u: u if is3d else u.squeeze(2))(t.permute(0, 4, 1, 2, 3))
+    results = {}
+    old = HF.CONV_IMPLICIT
+    try:
+        for path in ("implicit", "im2col"):
+            HF.CONV_IMPLICIT = path == "implicit"
+            xd = to_cl(x.to(dev()).to(dtype)).requires_grad_(True)
+            wd = w.to(dev()).to(dtype).float().requires_grad_(True)
+            bd = b.to(dev()).to(dtype).float().requires_grad_(True)
+            y = HF.ConvFn.apply(xd, wd, bd, None, geom, dtype, dtype)
+            (y.float() * to_cl(dy.to(dev()).to(dtype)).float()).sum().backward()
+            results[path] = (from_cl(y.detach()).float().cpu(), from_cl(xd.grad).float().cpu(), wd.grad.cpu(), bd.grad.cpu())
+    finally:
+        HF.CONV_IMPLICIT = old
+    tol = 1e-4 if dtype == torch.float32 else 2e-2
+    refs = (y_ref.detach(), xr.grad, wr.grad, br.grad)
+    for path, got in results.items():
+        for name, a, r in zip(("y", "dx", "dw", "db"), got, refs):
+            err = ((a.double() - r).abs().max() / (r.abs().max() + 1e-12)).item()
+            assert err < tol, (path, name, err)
+    assert torch.equal(results["implicit"][0], results["im2col"][0])
 
 
 @pytest.mark.parametrize("seed", range(8))
