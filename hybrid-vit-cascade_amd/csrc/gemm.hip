@@ -22,7 +22,17 @@
 namespace hvc {
 namespace {
 
-constexpr int kBM = 128, kBN = 128;
+// Workgroup tile = WM x WN wavefronts (4 in all), each computing MI x NI MFMA 32x32 blocks.
+template <int WM_, int WN_, int MI_, int NI_>
+struct TileCfg {
+    static constexpr int WM = WM_, WN = WN_, MI = MI_, NI = NI_, BM = WM_ * MI_ * 32, BN = WN_ * NI_ * 32;
+    static_assert(WM_ * WN_ == 4, "four wavefronts per workgroup");
+};
+using Tile128 = TileCfg<2, 2, 2, 2>;       // 128 x 128: every dense projection
+using TileN32 = TileCfg<4, 1, 2, 1>;       // 256 x 32 : implicit-GEMM convolutions with <= 32 output channels
+using TileN64 = TileCfg<4, 1, 2, 2>;       // 256 x 64 : ... with <= 64 output channels
+using TileM32 = TileCfg<1, 4, 1, 1>;       // 32 x 128 : their weight gradients (rows = output channels)
+using TileM64 = TileCfg<1, 4, 2, 1>;       // 64 x 128
 
 
 // n (<= 8) consecutive elements <-> 8 floats; vec: one 16-byte (bf16) / two 16-byte (fp32) accesses.
@@ -55,15 +65,18 @@ __device__ __forceinline__ void store_n(T* p, const float (&v)[8], int n, bool v
     }
 }
 
-// Operand tile loader.  KM = false: LDS image [128 rows][BK] (row = i, k contiguous);
-//                       KM = true : LDS image [BK rows][128] (row = k, i contiguous).
-template <typename T, int BK, bool KM>
+// Operand tile loader (EXT = tile extent along the operand's non-contracted index).
+//                       KM = false: LDS image [EXT rows][BK] (row = i, k contiguous);
+//                       KM = true : LDS image [BK rows][EXT] (row = k, i contiguous).
+template <typename T, int BK, bool KM, int EXT = 128>
 struct OperandTile {
     static constexpr int NS = NSplit<T>::value;
-    static constexpr int CW = KM ? 128 : BK;
-    static constexpr int ROWS = KM ? BK : 128;
+    static constexpr int CW = KM ? EXT : BK;
+    static constexpr int ROWS = KM ? BK : EXT;
     static constexpr int CPR = CW / 8;
-    static constexpr int CPT = ROWS * CPR / 256;
+    static constexpr int NCH = ROWS * CPR;                 // 16-byte chunks per tile
+    static constexpr int CPT = (NCH + 255) / 256;
+    static constexpr bool FULL = NCH % 256 == 0;           // every thread owns CPT chunks (else: ids >= NCH are idle)
     static constexpr int IMG = ROWS * CW;
     Chunk8<T> reg[2][CPT];  // two staging sets: tiles are fetched two k-steps ahead of their use
     const T* next;          // this thread's first chunk in the next k-tile (interior fast path)
@@ -82,13 +95,14 @@ struct OperandTile {
     // incrementally advanced addresses; edge tiles go through the per-chunk bounds path.
     template <int SET>
     __device__ __forceinline__ void issue(const T* base, int64_t ld, int i0, int ni, int k0, int nk, bool vec, int tid) {
-        if (vec && i0 + 128 <= ni && k0 + BK <= nk) {
+        if (FULL && vec && i0 + EXT <= ni && k0 + BK <= nk) {
 #pragma unroll
             for (int c = 0; c < CPT; ++c) reg[SET][c] = load_chunk<T>(next + c * rstep, 8, true);
         } else {
 #pragma unroll
             for (int c = 0; c < CPT; ++c) {
                 int id = tid + 256 * c;
+                if (!FULL && id >= NCH) break;
                 int row = id / CPR, ch = id % CPR;
                 if constexpr (!KM) {
                     int i = i0 + row, k = k0 + ch * 8;
@@ -108,6 +122,7 @@ struct OperandTile {
 #pragma unroll
         for (int c = 0; c < CPT; ++c) {
             int id = tid + 256 * c;
+            if (!FULL && id >= NCH) break;
             int row = id / CPR, ch = id % CPR;
             bf16x8 im[NS];
             chunk_split<T>(reg[SET][c], im);
@@ -128,14 +143,23 @@ __device__ __forceinline__ uint32_t fdiv(uint32_t n, const FastDiv& f) { return 
 // the patch matrix of spatial.hip's im2col never exists in HBM).  Same LDS image and fragments as OperandTile.
 //   KM = false: tile rows = patch rows m (output positions), chunk = 8 channels of one tap.  A thread keeps the decoded
 //               positions of its CPT rows for the whole k loop and decodes its (tap, channel) once per k-tile.
-//   KM = true : tile rows = contraction index = patch rows m, columns = patch columns.  A thread's (tap, channel) is
-//               fixed for the whole kernel; its CPT patch rows are decoded per k-tile.
-template <typename T, int BK, bool KM>
-struct GatherTile : OperandTile<T, BK, KM> {
-    using Base = OperandTile<T, BK, KM>;
+//   KM = true : tile rows = contraction index = patch rows m, columns = patch columns.  Eight consecutive lanes cover
+//               128 bytes of one patch row; a thread owns NG column groups (their taps are fixed for the whole kernel)
+//               of RPT patch rows, which it decodes once per k-tile.
+template <typename T, int BK, bool KM, int EXT>
+struct GatherTile : OperandTile<T, BK, KM, EXT> {
+    using Base = OperandTile<T, BK, KM, EXT>;
     static constexpr int CPT = Base::CPT, CPR = Base::CPR;
-    int pd[CPT], ph[CPT], pw[CPT], pb[CPT];    // KM = false: per-row first source coordinate (o * stride - pad), b * SD
-    int kd, kh, kw, kc;                         // KM = true : this thread's tap and first channel (kd < 0: beyond K)
+    static_assert(Base::FULL, "gathered tiles keep every thread busy");
+    static_assert(!KM || CPR % 8 == 0, "k-major gather: column groups of 8 chunks");
+    static constexpr int NG = KM ? CPR / 8 : 1;            // KM = true: column groups per thread
+    static constexpr int RPT = KM ? CPT / NG : CPT;        // rows per thread
+    int pd[RPT], ph[RPT], pw[RPT], pb[RPT];                // KM = false: per-row first source coordinate (o * stride - pad), b * SD
+    int kd[NG], kh[NG], kw[NG], kc[NG];                    // KM = true : per-group tap and first channel (kd < 0: beyond K)
+
+    // KM = true: chunk c of thread tid sits at tile row (tid / 8) + 32 * (c / NG), chunk column (tid % 8) + 8 * (c % NG)
+    static __device__ __forceinline__ int km_row(int tid, int c) { return (tid >> 3) + 32 * (c / NG); }
+    static __device__ __forceinline__ int km_ch(int tid, int c) { return (tid & 7) + 8 * (c % NG); }
 
     static __device__ __forceinline__ void taps_of(const ConvGather& cg, int k, int& d, int& h, int& w, int& c) {
         const uint32_t tap = fdiv((uint32_t)k, cg.dC);
@@ -173,9 +197,12 @@ struct GatherTile : OperandTile<T, BK, KM> {
 #pragma unroll
             for (int c = 0; c < CPT; ++c) rows_of(cg, (int64_t)x0 + (tid + 256 * c) / CPR, pd[c], ph[c], pw[c], pb[c]);
         } else {
-            const int k = x0 + (tid % CPR) * 8;
-            kd = -1;
-            if (k < cg.K) taps_of(cg, k, kd, kh, kw, kc);
+#pragma unroll
+            for (int gidx = 0; gidx < NG; ++gidx) {
+                const int k = x0 + km_ch(tid, gidx) * 8;
+                kd[gidx] = -1;
+                if (k < cg.K) taps_of(cg, k, kd[gidx], kh[gidx], kw[gidx], kc[gidx]);
+            }
         }
     }
     // k0: first contraction index of the tile (KM = false: patch column;  KM = true: patch row)
@@ -194,22 +221,40 @@ struct GatherTile : OperandTile<T, BK, KM> {
             }
         } else {
 #pragma unroll
-            for (int c = 0; c < CPT; ++c) {
+            for (int rr = 0; rr < RPT; ++rr) {
                 int d0, h0, w0, b0;
-                rows_of(cg, k0 + (tid + 256 * c) / CPR, d0, h0, w0, b0);
-                this->reg[SET][c] = kd < 0 ? zero_chunk<T>() : fetch(cg, b0, d0 + kd, h0 + kh, w0 + kw, kc);
+                rows_of(cg, k0 + km_row(tid, rr * NG), d0, h0, w0, b0);
+#pragma unroll
+                for (int gidx = 0; gidx < NG; ++gidx)
+                    this->reg[SET][rr * NG + gidx] =
+                        kd[gidx] < 0 ? zero_chunk<T>() : fetch(cg, b0, d0 + kd[gidx], h0 + kh[gidx], w0 + kw[gidx], kc[gidx]);
+            }
+        }
+    }
+    template <int SET>
+    __device__ __forceinline__ void commit(bf16* images, int tid) {
+        if constexpr (!KM) {
+            Base::template commit<SET>(images, tid);
+        } else {
+#pragma unroll
+            for (int c = 0; c < CPT; ++c) {
+                bf16x8 im[Base::NS];
+                chunk_split<T>(this->reg[SET][c], im);
+#pragma unroll
+                for (int s = 0; s < Base::NS; ++s) tile_store<Base::CW>(images + s * Base::IMG, km_row(tid, c), km_ch(tid, c), im[s]);
             }
         }
     }
 };
 
-template <typename TI, typename TO, bool AKM, bool BKM, int GATHER>
+template <typename TI, typename TO, bool AKM, bool BKM, int GATHER, typename Cfg>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
     constexpr int NS = NSplit<TI>::value;
     constexpr int BK = sizeof(TI) == 2 ? 64 : 32;
+    constexpr int kBM = Cfg::BM, kBN = Cfg::BN, MI = Cfg::MI, NI = Cfg::NI;
     static_assert(GATHER == 0 || (GATHER == 1 && !AKM && !BKM) || (GATHER == 2 && AKM && BKM), "gather variants: forward / dW layouts only");
-    using TA = std::conditional_t<GATHER == 1, GatherTile<TI, BK, false>, OperandTile<TI, BK, AKM>>;
-    using TB = std::conditional_t<GATHER == 2, GatherTile<TI, BK, true>, OperandTile<TI, BK, BKM>>;
+    using TA = std::conditional_t<GATHER == 1, GatherTile<TI, BK, false, kBM>, OperandTile<TI, BK, AKM, kBM>>;
+    using TB = std::conditional_t<GATHER == 2, GatherTile<TI, BK, true, kBN>, OperandTile<TI, BK, BKM, kBN>>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16* lds = reinterpret_cast<bf16*>(smem);
     constexpr int A_SZ = NS * TA::IMG, B_SZ = NS * TB::IMG;
@@ -218,7 +263,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
     auto Bt = [&](int buf) { return lds + buf * (A_SZ + B_SZ) + A_SZ; };
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
     const int r = lane & 31, h = lane >> 5;
 
     // XCD-aware work order.  Workgroup b runs on XCD b % 8 (round-robin dispatch), so XCD x is given the
@@ -279,11 +324,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
     tb.template commit<0>(Bt(0), tid);
     __syncthreads();
 
-    f32x16 acc[2][2];
+    f32x16 acc[MI][NI];
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
+        for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[mi][ni][i] = 0.f;
 
@@ -296,18 +341,18 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
         }
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
-            bf16x8 af[NS][2], bfr[NS][2];
+            bf16x8 af[NS][MI], bfr[NS][NI];
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
 #pragma unroll
-                for (int mi = 0; mi < 2; ++mi) af[s][mi] = TA::frag(At(buf) + s * TA::IMG, 64 * wm + 32 * mi, ks, lane);
+                for (int mi = 0; mi < MI; ++mi) af[s][mi] = TA::frag(At(buf) + s * TA::IMG, 32 * (MI * wm + mi), ks, lane);
 #pragma unroll
-                for (int ni = 0; ni < 2; ++ni) bfr[s][ni] = TB::frag(Bt(buf) + s * TB::IMG, 64 * wn + 32 * ni, ks, lane);
+                for (int ni = 0; ni < NI; ++ni) bfr[s][ni] = TB::frag(Bt(buf) + s * TB::IMG, 32 * (NI * wn + ni), ks, lane);
             }
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
+            for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < 2; ++ni)
+                for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
                     for (int sa = 0; sa < NS; ++sa)
 #pragma unroll
@@ -331,17 +376,20 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
 
     // ---- epilogue: stage the 128 x 128 fp32 tile through LDS (the operand buffers are free now) so that
     // every global access of the epilogue is a 16/32-byte row segment instead of a 2/4-byte column element.
-    float* stage = reinterpret_cast<float*>(smem);          // [128][128] fp32 = 64 KiB = the operand double buffer
+    float* stage = reinterpret_cast<float*>(smem);          // [BM][BN] fp32 (128 x 128: 64 KiB = the operand double buffer)
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
+        for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
             for (int x = 0; x < 16; ++x)
-                stage[(64 * wm + 32 * mi + acc_row(x, h)) * kBN + 64 * wn + 32 * ni + r] = acc[mi][ni][x];
+                stage[(32 * (MI * wm + mi) + acc_row(x, h)) * kBN + 32 * (NI * wn + ni) + r] = acc[mi][ni][x];
     __syncthreads();
 
-    const int ch = tid & 15;                 // 8-column chunk of the tile row handled by this thread
+    constexpr int CHN = kBN / 8;             // 8-column chunks per tile row
+    constexpr int RS = 256 / CHN;            // tile rows covered by one pass of the workgroup
+    const int ch = tid % CHN;                // 8-column chunk of the tile row handled by this thread
+    const int trow = tid / CHN;
     const int j = j0 + ch * 8;
     if (j >= g.N) return;
     const int nj = min(8, g.N - j);
@@ -349,7 +397,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
 
     if (g.splitk > 1) {   // raw fp32 partial tile -> slab `split` of the workspace; reduced by splitk_reduce_kernel
         float* ws = g.workspace + (size_t)split * g.M * g.N;
-        for (int row = tid >> 4; row < kBM; row += 16) {
+        for (int row = trow; row < kBM; row += RS) {
             const int i = i0 + row;
             if (i >= g.M) break;
             const float* sp = stage + row * kBN + ch * 8;
@@ -373,25 +421,25 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
 
     // Issue every global read of the epilogue (residual rows, saved pre-activations) before touching the staged tile,
     // so the 8 row segments of a thread cost one memory round trip instead of eight dependent ones.
-    constexpr int RPT = kBM / 16;           // rows per thread
+    constexpr int RPT = kBM / RS;           // rows per thread
     float rres[RPT][8], rpre[RPT][8];
     if (g.residual) {
 #pragma unroll
         for (int it = 0; it < RPT; ++it) {
-            const int i = i0 + (tid >> 4) + 16 * it;
+            const int i = i0 + trow + RS * it;
             if (i < g.M) load_n<float>(g.residual + (int64_t)(g.residual_rows > 0 ? i % g.residual_rows : i) * g.ldr + j, rres[it], nj, vec);
         }
     }
     if (g.act == kActGeluGrad) {
 #pragma unroll
         for (int it = 0; it < RPT; ++it) {
-            const int i = i0 + (tid >> 4) + 16 * it;
+            const int i = i0 + trow + RS * it;
             if (i < g.M) load_n<TO>(auxp + (int64_t)i * g.ldc + j, rpre[it], nj, vec);
         }
     }
 #pragma unroll
     for (int it = 0; it < RPT; ++it) {
-        const int row = (tid >> 4) + 16 * it;
+        const int row = trow + RS * it;
         const int i = i0 + row;
         if (i >= g.M) break;
         float v[8];
@@ -461,13 +509,14 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs g) {
     }
 }
 
-template <typename TI, typename TO, bool AKM, bool BKM, int GATHER = 0>
+template <typename TI, typename TO, bool AKM, bool BKM, int GATHER = 0, typename Cfg = Tile128>
 hipError_t launch(const GemmArgs& g_in, hipStream_t st) {
     GemmArgs g = g_in;
     constexpr int NS = NSplit<TI>::value;
     constexpr int BK = sizeof(TI) == 2 ? 64 : 32;
-    const size_t lds = (size_t)2 * 2 * NS * 128 * BK * sizeof(bf16);
-    auto k = gemm_kernel<TI, TO, AKM, BKM, GATHER>;
+    constexpr int kBM = Cfg::BM, kBN = Cfg::BN;
+    const size_t lds = (size_t)2 * NS * (kBM + kBN) * BK * sizeof(bf16);
+    auto k = gemm_kernel<TI, TO, AKM, BKM, GATHER, Cfg>;
     static thread_local bool lds_raised = false;      // per instantiation; sticky attribute, set once (also keeps it out of graph captures)
     if (lds > 48 * 1024 && !lds_raised) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -504,8 +553,20 @@ hipError_t launch(const GemmArgs& g_in, hipStream_t st) {
 
 template <typename TI, typename TO>
 hipError_t launch_layout(const GemmArgs& g, hipStream_t st) {
-    if (g.gather == 1) return (g.a_kmajor || g.b_kmajor) ? hipErrorInvalidValue : launch<TI, TO, false, false, 1>(g, st);
-    if (g.gather == 2) return (!g.a_kmajor || !g.b_kmajor) ? hipErrorInvalidValue : launch<TI, TO, true, true, 2>(g, st);
+    // Implicit-GEMM convolutions: tall tiles for few output channels (forward, dx), flat ones for their weight gradients, so
+    // that a 32-channel layer does not multiply 96 columns of padding.
+    if (g.gather == 1) {
+        if (g.a_kmajor || g.b_kmajor) return hipErrorInvalidValue;
+        if (g.N <= 32 && g.M >= 1024) return launch<TI, TO, false, false, 1, TileN32>(g, st);
+        if (g.N <= 64 && g.M >= 1024) return launch<TI, TO, false, false, 1, TileN64>(g, st);
+        return launch<TI, TO, false, false, 1>(g, st);
+    }
+    if (g.gather == 2) {
+        if (!g.a_kmajor || !g.b_kmajor) return hipErrorInvalidValue;
+        if (g.M <= 32) return launch<TI, TO, true, true, 2, TileM32>(g, st);
+        if (g.M <= 64) return launch<TI, TO, true, true, 2, TileM64>(g, st);
+        return launch<TI, TO, true, true, 2>(g, st);
+    }
     if (g.a_kmajor) return g.b_kmajor ? launch<TI, TO, true, true>(g, st) : launch<TI, TO, true, false>(g, st);
     return g.b_kmajor ? launch<TI, TO, false, true>(g, st) : launch<TI, TO, false, false>(g, st);
 }
@@ -513,7 +574,8 @@ hipError_t launch_layout(const GemmArgs& g, hipStream_t st) {
 }  // namespace
 
 int64_t gemm_workspace_floats(int M, int N, int K) {
-    const int tiles = ((M + kBM - 1) / kBM) * ((N + kBN - 1) / kBN);
+    // 128 x 128 tiles; the flat weight-gradient tiles (M <= 64 rows, 128 columns) give the same tile count
+    const int tiles = ((M + 127) / 128) * ((N + 127) / 128);
     if (tiles > 128 || K < 8 * 32) return 0;
     int want = (512 + tiles - 1) / tiles;
     const int nkt = (K + 31) / 32;

@@ -1179,6 +1179,8 @@ def test_conv_layers_random_geometry(seed, conv_path):
     (False, 3, 64, 128, 3, 1, 1, (40, 36)),        # X-ray stem layer (diagnostic_losses.py:87)
     (False, 2, 128, 256, 3, 1, 1, (21, 19)),
     (True, 1, 16, 8, 1, 1, 0, (9, 10, 11)),        # 1x1x1
+    (True, 1, 16, 24, 3, 1, 1, (12, 11, 10)),      # 24 output channels: ragged narrow tiles (256 x 32 forward / dx, 32 x 128 dW)
+    (True, 1, 40, 56, 3, 1, 1, (9, 12, 13)),       # 256 x 64 and 64 x 128 tiles with ragged channel counts
 ])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_conv_implicit_gemm_vs_fp64_and_im2col(cfg, dtype):
