@@ -2,7 +2,7 @@
 a volume into tokens, the LN + Linear(C,1) head with the trilinear upsample, and the 2-D X-ray CNN
 stem.  The module classes keep the reference's nn.Sequential containers (for parameter names and
 initialisation); these functions walk the containers and run every layer on the HIP kernels, with
-activations held CHANNELS-LAST so that each convolution is im2col + MFMA GEMM and the last stem
+activations held CHANNELS-LAST so that each convolution is an (implicit) MFMA GEMM and the last stem
 layer's output is already the (B, N, C) token matrix.
 
 STAGE_BACKEND records what executes each stage (reported by bench.py): "hip" = hand-written gfx950
@@ -15,19 +15,19 @@ from . import functional as HF
 from . import ops
 
 STAGE_BACKEND = {
-    "voxel_embed_conv3d": "hip (im2col + MFMA GEMM)",
+    "voxel_embed_conv3d": "hip (implicit MFMA GEMM; first layer im2col + GEMM)",
     "voxel_embed_groupnorm_silu": "hip",
     "tokens_pos_embed": "hip (GEMM epilogue)",
     "head_layernorm": "hip",
     "head_proj": "hip",
     "trilinear_upsample": "hip",
-    "xray_conv2d": "hip (im2col + MFMA GEMM)",
+    "xray_conv2d": "hip (implicit MFMA GEMM; first layer im2col + GEMM)",
     "xray_batchnorm_relu_pool": "hip",
     "xray_view_mean_gap": "hip (fused)",
     "drr_projection_resize_l1_mse": "hip (fused resize + reduction)",
     "frequency_loss": "rocFFT + hip (fused magnitude / mask / L1)",
     "ssim_l1_loss": "hip",
-    "cascade_glue_conv_gn_gelu_upsample": "hip (slab-wise im2col above 2 GiB)",
+    "cascade_glue_conv_gn_gelu_upsample": "hip (implicit MFMA GEMM; single-channel layers slab-wise im2col above 2 GiB)",
 }
 
 
