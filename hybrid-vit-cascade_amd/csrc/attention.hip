@@ -30,11 +30,6 @@
 #include "hvc_kernels.h"
 #include "attn_dropout.hip.h"
 
-#ifdef HVC_SETPRIO
-#define PRIO(x) __builtin_amdgcn_s_setprio(x)
-#else
-#define PRIO(x)
-#endif
 namespace hvc {
 
 namespace {
@@ -495,14 +490,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const AttnArgs a_in) 
         constexpr int KOFF = (buf * 2 + 0) * TILE, VOFF = (buf * 2 + 1) * TILE;
         if (t + 1 < nt) issue((t + 1) * kKT2);
         f32x16 st[2] = {negm[0], negm[1]};
-        PRIO(1);
 #pragma unroll
         for (int s = 0; s < D / 16; ++s) {
             const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kaddr[s] + KOFF);
 #pragma unroll
             for (int blk = 0; blk < 2; ++blk) st[blk] = mfma32(kf, qf[blk][0][s], st[blk]);
         }
-        PRIO(0);
         if constexpr (MASK) {
 #pragma unroll
             for (int blk = 0; blk < 2; ++blk)
@@ -573,11 +566,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const AttnArgs a_in) 
                         pf[0] = __builtin_bit_cast(bf16x8, w);
                     }
                 }
-                PRIO(1);
-#pragma unroll
+        #pragma unroll
                 for (int dt = 0; dt < D / 32; ++dt) o[blk][dt] = mfma32(vfr[dt], pf[0], o[blk][dt]);
-                PRIO(0);
-            }
+                    }
         }
         if (t + 1 < nt) commit(buf ^ 1);
         __syncthreads();
@@ -967,8 +958,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a_i
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { s[4 * g + j] = l4[j]; nd[4 * g + j] = d4[j]; dp[4 * g + j] = DROP ? 0.f : d4[j]; }
             }
-            PRIO(1);
-#pragma unroll
+    #pragma unroll
             for (int ks = 0; ks < D / 16; ++ks) {
 #pragma unroll
                 for (int sa = 0; sa < NS; ++sa) {
@@ -982,8 +972,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a_i
                         }
                 }
             }
-            PRIO(0);
-            float pd[16], ds[16];
+                float pd[16], ds[16];
 #pragma unroll
             for (int i = 0; i < 16; ++i) s[i] = __builtin_amdgcn_exp2f(s[i]);      // all exponentials ahead of the select / multiply pass (-1.3 % same-box)
 #pragma unroll
@@ -1020,8 +1009,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a_i
                 bf16x8 pf[NS], dsf[NS];
                 acc_split<NS>(x, pf);
                 acc_split<NS>(y, dsf);
-                PRIO(1);
-#pragma unroll
+        #pragma unroll
                 for (int dt = 0; dt < D / 32; ++dt) {
 #pragma unroll
                     for (int sb = 0; sb < NS; ++sb) {
@@ -1036,8 +1024,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a_i
                             }
                     }
                 }
-                PRIO(0);
-            }
+                    }
         }
         if (t + 1 < nt) {
             ql.commit(Qt(buf ^ 1), tid);
