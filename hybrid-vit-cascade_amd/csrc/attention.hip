@@ -566,9 +566,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const AttnArgs a_in) 
                         pf[0] = __builtin_bit_cast(bf16x8, w);
                     }
                 }
-        #pragma unroll
+#pragma unroll
                 for (int dt = 0; dt < D / 32; ++dt) o[blk][dt] = mfma32(vfr[dt], pf[0], o[blk][dt]);
-                    }
+            }
         }
         if (t + 1 < nt) commit(buf ^ 1);
         __syncthreads();
@@ -958,7 +958,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a_i
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { s[4 * g + j] = l4[j]; nd[4 * g + j] = d4[j]; dp[4 * g + j] = DROP ? 0.f : d4[j]; }
             }
-    #pragma unroll
+#pragma unroll
             for (int ks = 0; ks < D / 16; ++ks) {
 #pragma unroll
                 for (int sa = 0; sa < NS; ++sa) {
@@ -972,7 +972,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a_i
                         }
                 }
             }
-                float pd[16], ds[16];
+            float pd[16], ds[16];
 #pragma unroll
             for (int i = 0; i < 16; ++i) s[i] = __builtin_amdgcn_exp2f(s[i]);      // all exponentials ahead of the select / multiply pass (-1.3 % same-box)
 #pragma unroll
@@ -1009,7 +1009,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a_i
                 bf16x8 pf[NS], dsf[NS];
                 acc_split<NS>(x, pf);
                 acc_split<NS>(y, dsf);
-        #pragma unroll
+#pragma unroll
                 for (int dt = 0; dt < D / 32; ++dt) {
 #pragma unroll
                     for (int sb = 0; sb < NS; ++sb) {
@@ -1024,7 +1024,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a_i
                             }
                     }
                 }
-                    }
+            }
         }
         if (t + 1 < nt) {
             ql.commit(Qt(buf ^ 1), tid);
