@@ -45,6 +45,7 @@ constexpr int kQB = 128;    // rows per workgroup
 constexpr int kLotPart = 32 + 8;           // 16-bit lots from one part's start to the next (32 keys + 16 bytes)
 constexpr int kLotStride = 4 * kLotPart;   // lots per tile row
 constexpr float kRescaleLog2 = 6.f;   // deferred running-max update: P stays <= 2^6 between rescales
+constexpr float kRescaleSum = 1024.f; // 64-row forward: the same test on a half-row sum of 16 probabilities (16 * 2^6)
 
 // 8 elements of row n (zeros when n >= nrows).  VEC: one clamped 16-byte load + select (no branch).
 template <typename T, bool VEC>
@@ -489,32 +490,61 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const AttnArgs a_in) 
         constexpr int buf = decltype(buf_tag)::value;            // = t & 1 = which half of the 64-key hash tile
         constexpr int KOFF = (buf * 2 + 0) * TILE, VOFF = (buf * 2 + 1) * TILE;
         if (t + 1 < nt) issue((t + 1) * kKT2);
-        f32x16 st[2] = {negm[0], negm[1]};
+        f32x16 st[2];
+        auto scores = [&]() {                                     // S^T = K Q^T in exp2 units, minus the reference exponent
+            st[0] = negm[0];
+            st[1] = negm[1];
 #pragma unroll
-        for (int s = 0; s < D / 16; ++s) {
-            const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kaddr[s] + KOFF);
+            for (int s = 0; s < D / 16; ++s) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kaddr[s] + KOFF);
 #pragma unroll
-            for (int blk = 0; blk < 2; ++blk) st[blk] = mfma32(kf, qf[blk][0][s], st[blk]);
-        }
-        if constexpr (MASK) {
+                for (int blk = 0; blk < 2; ++blk) st[blk] = mfma32(kf, qf[blk][0][s], st[blk]);
+            }
+            if constexpr (MASK) {
 #pragma unroll
-            for (int blk = 0; blk < 2; ++blk)
+                for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
-                for (int i = 0; i < 16; ++i)
-                    if (t * kKT2 + acc_row(i, h) >= a.Nk) st[blk][i] = -INFINITY;
-        }
-        float mloc[2];
-#pragma unroll
-        for (int blk = 0; blk < 2; ++blk) {
-            float m = -INFINITY;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) m = fmaxf(m, st[blk][i]);
-            mloc[blk] = fmaxf(m, __shfl_xor(m, 32, 64));
-        }
-        if (t == 0 || __any(fmaxf(mloc[0], mloc[1]) > kRescaleLog2)) {
+                    for (int i = 0; i < 16; ++i)
+                        if (t * kKT2 + acc_row(i, h) >= a.Nk) st[blk][i] = -INFINITY;
+            }
+        };
+        float rs[2];
+        auto exps = [&]() {
 #pragma unroll
             for (int blk = 0; blk < 2; ++blk) {
-                const float shift = t == 0 ? mloc[blk] : fmaxf(mloc[blk], 0.f);
+                // two plain add chains per block: hipcc otherwise pairs the two blocks' sums into one dependent v_pk_add_f32
+                // chain (1.5 issue slots per instruction plus wait states between dependent packed ops)
+                float acc0 = 0.f, acc1 = 0.f;
+#pragma unroll
+                for (int i = 0; i < 16; i += 2) {
+                    const float p0 = __builtin_amdgcn_exp2f(st[blk][i]), p1 = __builtin_amdgcn_exp2f(st[blk][i + 1]);
+                    asm("v_add_f32 %0, %0, %1" : "+v"(acc0) : "v"(p0));
+                    asm("v_add_f32 %0, %0, %1" : "+v"(acc1) : "v"(p1));
+                    st[blk][i] = p0;
+                    st[blk][i + 1] = p1;
+                }
+                rs[blk] = acc0 + acc1;
+            }
+        };
+        scores();
+        // Steady state: no row maximum at all.  The exponentials are taken against the current reference and their row
+        // sums (needed anyway) tell whether some score outgrew it: a probability above 2^kRescaleLog2 pushes its half-row
+        // sum past that bound, an overflow makes it inf, a NaN fails the comparison.  Only then (and on the first tile, which
+        // has no reference yet) are the scores rebuilt and the reference moved to the new maximum.
+        bool move_ref = t == 0;
+        if (!move_ref) {
+            exps();
+            move_ref = __any(!(fmaxf(rs[0], rs[1]) <= kRescaleSum));
+            if (move_ref) scores();
+        }
+        if (move_ref) {
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk) {
+                float m = -INFINITY;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) m = fmaxf(m, st[blk][i]);
+                m = fmaxf(m, __shfl_xor(m, 32, 64));
+                const float shift = t == 0 ? m : fmaxf(m, 0.f);
                 const float alpha = t == 0 ? 1.f : __builtin_amdgcn_exp2f(-shift);
                 l[blk] *= alpha;
 #pragma unroll
@@ -527,18 +557,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const AttnArgs a_in) 
 #pragma unroll
                 for (int i = 0; i < 16; ++i) st[blk][i] -= shift;
             }
+            exps();
         }
-#pragma unroll
-        for (int blk = 0; blk < 2; ++blk) {
-            float rs = 0.f;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const float p = __builtin_amdgcn_exp2f(st[blk][i]);
-                rs += p;
-                st[blk][i] = p;
-            }
-            l[blk] += rs;
-        }
+        l[0] += rs[0];
+        l[1] += rs[1];
         // O^T[d][q] += V^T P^T: each transposed V fragment serves both query blocks
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {

@@ -1481,8 +1481,10 @@ def test_direct_model_full_size_128_forward_backward_batch2():
 
 
 @pytest.mark.timeout(1100)
-def test_progressive_trainer_stage3_256_full_losses_with_checkpointing(tmp_path):
-    """BASELINE config #5 as a test (per-GPU slice, batch 1): one optimisation step of cascade stage 3 at 256^3 through
+@pytest.mark.parametrize("fp8", [False, True], ids=["bf16_attention", "fp8_attention"])
+def test_progressive_trainer_stage3_256_full_losses_with_checkpointing(tmp_path, fp8):
+    """BASELINE config #5 as a test (per-GPU slice, batch 1; with the "mi355x": {"fp8_attention": true} switch the attention
+    forward products run as e4m3 MFMAs, as the config names): one optimisation step of cascade stage 3 at 256^3 through
     train_progressive_4gpu.build_stage / train_step with gradient checkpointing (reference model_progressive.py:286-291,
     train_progressive_4gpu.py:214-219) and the full Stage3Loss (L1 + SSIM + TV + frequency + 0.3 DRR reprojection,
     loss_multiscale.py:384-432; the VGG term needs downloaded weights and is skipped with a notice).  Stages 1 and 2 are
@@ -1498,6 +1500,17 @@ def test_progressive_trainer_stage3_256_full_losses_with_checkpointing(tmp_path)
     torch.save({"model_state_dict": m1.state_dict()}, tmp_path / "stage1_best.pth")
     torch.save({"model_state_dict": m1.state_dict()}, tmp_path / "stage2_best.pth")
     del m1
+    from hvc import functional as HF
+    cfg.setdefault("mi355x", {})["fp8_attention"] = fp8
+    HF.set_fp8_attention(bool(cfg["mi355x"]["fp8_attention"]))            # what train_stage does with the config section
+    try:
+        _stage3_256_step(T, cfg, tmp_path, synthetic, fp8)
+    finally:
+        HF.set_fp8_attention(False)
+
+
+def _stage3_256_step(T, cfg, tmp_path, synthetic, fp8):
+    import copy
     model, crit, opt, _ = T.build_stage(cfg, 3, tmp_path, dev())
     model.train()
     assert model.stage3.use_gradient_checkpointing
@@ -1515,7 +1528,13 @@ def test_progressive_trainer_stage3_256_full_losses_with_checkpointing(tmp_path)
         if k in frozen and "running_" not in k and "num_batches" not in k:
             assert torch.equal(v, frozen[k]), k
     assert not torch.equal(model.stage3.vit_refiner.blocks[0].mlp[0].weight.detach(), w0)
-    print(f"stage-3 256^3 step: peak memory {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB, loss {float(losses['total_loss']):.4f}")
+    print(f"stage-3 256^3 step ({'fp8' if fp8 else 'bf16'} attention): peak memory {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB, "
+          f"loss {float(losses['total_loss']):.4f}")
+    # the same seeds, weights and batch: the e4m3 forward moves the step's loss by a few per cent at most
+    assert abs(float(losses["total_loss"]) - _STAGE3_LOSS.setdefault("bf16", float(losses["total_loss"]))) <= 0.05 * abs(_STAGE3_LOSS["bf16"])
+
+
+_STAGE3_LOSS = {}
 
 
 @pytest.mark.parametrize("mode", ["f32", "bf16"])
