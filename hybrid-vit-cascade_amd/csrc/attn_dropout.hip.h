@@ -51,6 +51,24 @@ __device__ __forceinline__ void drop_keep4(uint32_t mixed, int ts, bool (&keep)[
     keep[0] = drop_keep_lo(a, ts); keep[1] = drop_keep_hi(a, ts);
     keep[2] = drop_keep_lo(b, ts); keep[3] = drop_keep_hi(b, ts);
 }
+// out[e] = keep(e) ? x[e] : alt for the four consecutive keys of one group.  The low lots are tested by a true 16-bit compare
+// (v_cmp_ge_i16 reads bits 15:0 of both operands); written as `(int16_t)w >= (int16_t)ts` hipcc canonicalises the test into
+// a shift and a 32-bit compare, one more instruction per element pair.
+__device__ __forceinline__ float drop_select_lo(uint32_t w, int ts, float x, float alt) {
+    uint64_t m;
+    float r;
+    asm("v_cmp_ge_i16_e64 %0, %1, %2" : "=s"(m) : "v"(w), "v"(ts));
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(alt), "v"(x), "s"(m));
+    return r;
+}
+__device__ __forceinline__ void drop_select4(uint32_t mixed, int ts, const float (&x)[4], float alt, float (&out)[4]) {
+    uint32_t a, b;
+    drop_lots4(mixed, a, b);
+    out[0] = drop_select_lo(a, ts, x[0], alt);
+    out[1] = drop_keep_hi(a, ts) ? x[1] : alt;
+    out[2] = drop_select_lo(b, ts, x[2], alt);
+    out[3] = drop_keep_hi(b, ts) ? x[3] : alt;
+}
 // word of two lots -> word of two 16-bit keep masks (0xffff = keep).  tm1x2 = (ts - 1) in both halves:
 // sat(ts - 1 - lot) is negative exactly when lot >= ts, and its sign fills the half.
 typedef short i16x2 __attribute__((ext_vector_type(2)));
