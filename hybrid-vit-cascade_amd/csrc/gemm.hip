@@ -17,6 +17,7 @@
 // buffered with register-staged global loads issued one k-tile ahead.
 #include "hvc_common.hip.h"
 #include "hvc_kernels.h"
+#include <stdlib.h>
 #include <type_traits>
 
 namespace hvc {
@@ -551,6 +552,13 @@ hipError_t launch(const GemmArgs& g_in, hipStream_t st) {
     return hipGetLastError();
 }
 
+// HVC_GEMM_HALF_TILE=0 pins the 128 x 128 tile (A/B switch for scripts/gemm_vs_blas.py)
+inline bool use_half_tile(const GemmArgs& g) {
+    static const bool env_on = [] { const char* e = getenv("HVC_GEMM_HALF_TILE"); return !(e && e[0] == '0'); }();
+    const int64_t tiles = (int64_t)((g.M + 127) / 128) * ((g.N + 127) / 128);
+    return env_on && g.M > 64 && tiles < 384 && gemm_workspace_floats(g.M, g.N, g.K) == 0;   // split-K shapes keep their tile count
+}
+
 template <typename TI, typename TO>
 hipError_t launch_layout(const GemmArgs& g, hipStream_t st) {
     // Implicit-GEMM convolutions: tall tiles for few output channels (forward, dx), flat ones for their weight gradients, so
@@ -566,6 +574,12 @@ hipError_t launch_layout(const GemmArgs& g, hipStream_t st) {
         if (g.M <= 32) return launch<TI, TO, true, true, 2, TileM32>(g, st);
         if (g.M <= 64) return launch<TI, TO, true, true, 2, TileM64>(g, st);
         return launch<TI, TO, true, true, 2>(g, st);
+    }
+    // Shapes that give the 512 workgroup slots of the chip fewer than ~3/4 of a round of 128 x 128 tiles (the 64^3 model's
+    // token matrices: 16384 x 256 = 256 tiles) run on 64 x 128 tiles: twice the workgroups on the same latency chain.
+    if (use_half_tile(g)) {
+        if (g.a_kmajor) return g.b_kmajor ? launch<TI, TO, true, true, 0, TileM64>(g, st) : launch<TI, TO, true, false, 0, TileM64>(g, st);
+        return g.b_kmajor ? launch<TI, TO, false, true, 0, TileM64>(g, st) : launch<TI, TO, false, false, 0, TileM64>(g, st);
     }
     if (g.a_kmajor) return g.b_kmajor ? launch<TI, TO, true, true>(g, st) : launch<TI, TO, true, false>(g, st);
     return g.b_kmajor ? launch<TI, TO, false, true>(g, st) : launch<TI, TO, false, false>(g, st);

@@ -10,7 +10,7 @@ def timeit(fn, n=30):
     s.record()
     for _ in range(n): fn()
     e.record(); torch.cuda.synchronize(); return s.elapsed_time(e) / n * 1e3
-M = 65536
+M = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 for (N, K) in ((256, 256), (768, 256), (1024, 256), (256, 1024)):
     x = torch.randn(M, K, device=dev, dtype=torch.bfloat16); w = torch.randn(N, K, device=dev, dtype=torch.bfloat16)
     dy = torch.randn(M, N, device=dev, dtype=torch.bfloat16)
