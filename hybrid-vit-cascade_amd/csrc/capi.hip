@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/hvc_hip.h"
@@ -357,20 +358,23 @@ int hvc_conv_gemm(int mode, const void* src, const void* other, void* out, int B
     hvc::ConvGather& cg = g.cg;
     cg.src = src; cg.C = C; cg.SD = SD; cg.SH = SH; cg.SW = SW; cg.KD = KD; cg.KH = KH; cg.KW = KW; cg.stride = stride;
     cg.PD = PD; cg.PH = PH; cg.PW = PW; cg.flip = flip != 0; cg.M = cgeo.M; cg.K = (int)K64;
+    const int64_t src_bytes = (int64_t)B * SD * SH * SW * C * (in_dtype == HVC_BF16 ? 2 : 4);
+    static const bool force64 = [] { const char* e = getenv("HVC_CONV_FORCE_ADDR64"); return e && e[0] == '1'; }();   // test hook for the >= 4 GiB path
+    cg.bytes = (src_bytes < (1ll << 32) && !force64) ? (uint32_t)src_bytes : 0u;
     cg.dC = hvc::make_fastdiv((uint32_t)C); cg.dKW = hvc::make_fastdiv((uint32_t)KW); cg.dKH = hvc::make_fastdiv((uint32_t)KH);
     cg.dOW = hvc::make_fastdiv((uint32_t)cgeo.OW); cg.dOH = hvc::make_fastdiv((uint32_t)cgeo.OH); cg.dOD = hvc::make_fastdiv((uint32_t)cgeo.OD);
     g.C = out; g.ldc = ld_out; g.alpha = 1.f; g.act = 0;
     g.in_bf16 = in_dtype == HVC_BF16; g.out_bf16 = out_dtype == HVC_BF16;
     g.workspace = workspace; g.workspace_floats = workspace ? workspace_floats : 0;
     if (mode == 0) {            // out[M][N] = patches[M][K] . other[N][K]^T
-        g.gather = 1;
+        g.gather = cg.bytes ? 1 : 3;
         g.A = src; g.lda = K64; g.B = other; g.ldb = ld_other;
         g.M = (int)cgeo.M; g.N = N; g.K = (int)K64;
         g.bias = bias; g.residual = residual; g.ldr = ldr; g.residual_rows = residual_rows > 0 ? residual_rows : 0;
         g.rows_per_batch = g.M;
         g.vec_a = 1; g.vec_b = aligned16(other) && (ld_other % 8 == 0);
     } else {                    // out[N][K] = other[M][N]^T . patches[M][K]
-        g.gather = 2;
+        g.gather = cg.bytes ? 2 : 4;
         g.a_kmajor = g.b_kmajor = 1;
         g.A = other; g.lda = ld_other; g.B = src; g.ldb = K64;
         g.M = N; g.N = (int)K64; g.K = (int)cgeo.M;

@@ -34,6 +34,8 @@ using TileN32 = TileCfg<4, 1, 2, 1>;       // 256 x 32 : implicit-GEMM convoluti
 using TileN64 = TileCfg<4, 1, 2, 2>;       // 256 x 64 : ... with <= 64 output channels
 using TileM32 = TileCfg<1, 4, 1, 1>;       // 32 x 128 : their weight gradients (rows = output channels)
 using TileM64 = TileCfg<1, 4, 2, 1>;       // 64 x 128
+using TileM32W = TileCfg<1, 4, 1, 2>;      // 32 x 256 : weight gradients of wide patch matrices - a decoded patch row serves four
+using TileM64W = TileCfg<1, 4, 2, 2>;      // 64 x 256   column groups instead of two, twice the MFMAs per barrier
 
 
 // n (<= 8) consecutive elements <-> 8 floats; vec: one 16-byte (bf16) / two 16-byte (fp32) accesses.
@@ -147,7 +149,7 @@ __device__ __forceinline__ uint32_t fdiv(uint32_t n, const FastDiv& f) { return 
 //   KM = true : tile rows = contraction index = patch rows m, columns = patch columns.  Eight consecutive lanes cover
 //               128 bytes of one patch row; a thread owns NG column groups (their taps are fixed for the whole kernel)
 //               of RPT patch rows, which it decodes once per k-tile.
-template <typename T, int BK, bool KM, int EXT>
+template <typename T, int BK, bool KM, int EXT, bool BUF>
 struct GatherTile : OperandTile<T, BK, KM, EXT> {
     using Base = OperandTile<T, BK, KM, EXT>;
     static constexpr int CPT = Base::CPT, CPR = Base::CPR;
@@ -155,8 +157,17 @@ struct GatherTile : OperandTile<T, BK, KM, EXT> {
     static_assert(!KM || CPR % 8 == 0, "k-major gather: column groups of 8 chunks");
     static constexpr int NG = KM ? CPR / 8 : 1;            // KM = true: column groups per thread
     static constexpr int RPT = KM ? CPT / NG : CPT;        // rows per thread
-    int pd[RPT], ph[RPT], pw[RPT], pb[RPT];                // KM = false: per-row first source coordinate (o * stride - pad), b * SD
-    int kd[NG], kh[NG], kw[NG], kc[NG];                    // KM = true : per-group tap and first channel (kd < 0: beyond K)
+    // BUF (activation tensor below 4 GiB, the usual case): the gather is BRANCH-FREE.  A chunk's byte offset is
+    // (window origin of its patch row) + (offset of its tap) in wrapping 32-bit arithmetic - linear, so it is right
+    // whenever the tap lies inside the volume, edge rows included - and an out-of-volume tap gets an offset beyond the
+    // buffer, for which buffer_load returns zeros: no lane- or wave-level branch around the loads (branches split the
+    // k loop into basic blocks, at whose joins hipcc waits for every load in flight - the prefetch turns synchronous).
+    uint32_t org[RPT];                                     // KM = false: element offset of the row's window origin (mod 2^32)
+    int pd[RPT], ph[RPT], pw[RPT], pb[RPT];                // KM = false: first source coordinate (o * stride - pad), b * SD
+    int kd[NG], kh[NG], kw[NG], kc[NG];                    // KM = true : per-group tap and first channel (kd = -2^24: beyond K)
+    uint32_t ktap[NG];                                     // KM = true : element offset of the group's tap inside a window
+    uint32_t inside;                                       // KM = false: bit c = chunk row c is interior for every lane of the wave
+    __amdgpu_buffer_rsrc_t rsrc;
 
     // KM = true: chunk c of thread tid sits at tile row (tid / 8) + 32 * (c / NG), chunk column (tid % 8) + 8 * (c % NG)
     static __device__ __forceinline__ int km_row(int tid, int c) { return (tid >> 3) + 32 * (c / NG); }
@@ -172,37 +183,66 @@ struct GatherTile : OperandTile<T, BK, KM, EXT> {
         d = (int)t3;
         if (cg.flip) { d = cg.KD - 1 - d; h = cg.KH - 1 - h; w = cg.KW - 1 - w; }
     }
-    static __device__ __forceinline__ void rows_of(const ConvGather& cg, int64_t m, int& d0, int& h0, int& w0, int& b0) {
-        if (m >= cg.M) { d0 = h0 = w0 = -(1 << 24); b0 = 0; return; }     // fails every bounds test
-        const uint32_t q1 = fdiv((uint32_t)m, cg.dOW);
-        const uint32_t ow = (uint32_t)m - q1 * cg.dOW.d;
+    static __device__ __forceinline__ uint32_t tap_offset(const ConvGather& cg, int d, int h, int w, int c) {
+        return (uint32_t)((d * cg.SH + h) * cg.SW + w) * (uint32_t)cg.C + (uint32_t)c;
+    }
+    static __device__ __forceinline__ void rows_of(const ConvGather& cg, int64_t m, int& d0, int& h0, int& w0, int& b0, uint32_t& origin) {
+        const bool live = m < cg.M;
+        const uint32_t mm = live ? (uint32_t)m : 0u;
+        const uint32_t q1 = fdiv(mm, cg.dOW);
+        const uint32_t ow = mm - q1 * cg.dOW.d;
         const uint32_t q2 = fdiv(q1, cg.dOH);
         const uint32_t oh = q1 - q2 * cg.dOH.d;
         const uint32_t b = fdiv(q2, cg.dOD);
         const uint32_t od = q2 - b * cg.dOD.d;
-        d0 = (int)od * cg.stride - cg.PD;
+        d0 = live ? (int)od * cg.stride - cg.PD : -(1 << 24);     // a dead row fails every bounds test
         h0 = (int)oh * cg.stride - cg.PH;
         w0 = (int)ow * cg.stride - cg.PW;
         b0 = (int)b * cg.SD;
+        origin = (uint32_t)(((b0 + d0) * cg.SH + h0) * cg.SW + w0) * (uint32_t)cg.C;
     }
+    static __device__ __forceinline__ bool in_volume(const ConvGather& cg, int sd, int sh, int sw) {
+        return (unsigned)sd < (unsigned)cg.SD && (unsigned)sh < (unsigned)cg.SH && (unsigned)sw < (unsigned)cg.SW;
+    }
+    // 64-bit fallback: lane-level bounds branch
     static __device__ __forceinline__ Chunk8<T> fetch(const ConvGather& cg, int b0, int sd, int sh, int sw, int c) {
-        const bool ok = (unsigned)sd < (unsigned)cg.SD && (unsigned)sh < (unsigned)cg.SH && (unsigned)sw < (unsigned)cg.SW;
-        if (!ok) return zero_chunk<T>();
+        if (!in_volume(cg, sd, sh, sw)) return zero_chunk<T>();
         const int64_t pos = ((int64_t)(b0 + sd) * cg.SH + sh) * cg.SW + sw;
         return load_chunk<T>(reinterpret_cast<const T*>(cg.src) + pos * cg.C + c, 8, true);
+    }
+    __device__ __forceinline__ Chunk8<T> fetch_buf(const ConvGather& cg, bool ok, uint32_t elem_off) const {
+        const uint32_t off = ok ? elem_off * (uint32_t)sizeof(T) : cg.bytes;      // = num_records: reads as zero
+        Chunk8<T> r;
+        if constexpr (sizeof(T) == 2) {
+            r.v = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0));
+        } else {
+            r.a = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0));
+            r.b = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 16, 0));
+        }
+        return r;
     }
 
     // x0: first tile row (KM = false: patch row i0;  KM = true: patch column j0)
     __device__ __forceinline__ void init(const ConvGather& cg, int x0, int tid) {
+        if constexpr (BUF) rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(cg.src), 0, cg.bytes, 0x00020000);
         if constexpr (!KM) {
+            inside = 0;
 #pragma unroll
-            for (int c = 0; c < CPT; ++c) rows_of(cg, (int64_t)x0 + (tid + 256 * c) / CPR, pd[c], ph[c], pw[c], pb[c]);
+            for (int c = 0; c < CPT; ++c) {
+                rows_of(cg, (int64_t)x0 + (tid + 256 * c) / CPR, pd[c], ph[c], pw[c], pb[c], org[c]);
+                // whole window inside the volume for every row of this wave's chunk row c: its bounds tests are skipped
+                // (a wave-uniform branch around vector arithmetic only - the loads stay outside of it)
+                const bool in = pd[c] >= 0 && ph[c] >= 0 && pw[c] >= 0 && pd[c] + cg.KD <= cg.SD && ph[c] + cg.KH <= cg.SH && pw[c] + cg.KW <= cg.SW;
+                if (__all(in)) inside |= 1u << c;
+            }
         } else {
 #pragma unroll
             for (int gidx = 0; gidx < NG; ++gidx) {
                 const int k = x0 + km_ch(tid, gidx) * 8;
-                kd[gidx] = -1;
-                if (k < cg.K) taps_of(cg, k, kd[gidx], kh[gidx], kw[gidx], kc[gidx]);
+                const bool live = k < cg.K;
+                taps_of(cg, live ? k : 0, kd[gidx], kh[gidx], kw[gidx], kc[gidx]);
+                ktap[gidx] = tap_offset(cg, kd[gidx], kh[gidx], kw[gidx], kc[gidx]);
+                if (!live) kd[gidx] = -(1 << 24);
             }
         }
     }
@@ -211,24 +251,35 @@ struct GatherTile : OperandTile<T, BK, KM, EXT> {
     __device__ __forceinline__ void issue(const ConvGather& cg, int64_t k0, int tid) {
         if constexpr (!KM) {
             const int k = (int)k0 + (tid % CPR) * 8;
-            if (k < cg.K) {
-                int d, h, w, cc;
-                taps_of(cg, k, d, h, w, cc);
+            const bool live = k < cg.K;
+            int d, h, w, cc;
+            taps_of(cg, live ? k : 0, d, h, w, cc);
+            if constexpr (BUF) {
+                const uint32_t t = tap_offset(cg, d, h, w, cc);
 #pragma unroll
-                for (int c = 0; c < CPT; ++c) this->reg[SET][c] = fetch(cg, pb[c], pd[c] + d, ph[c] + h, pw[c] + w, cc);
+                for (int c = 0; c < CPT; ++c) {
+                    bool ok = live;
+                    if (!(inside & (1u << c))) ok = ok && in_volume(cg, pd[c] + d, ph[c] + h, pw[c] + w);
+                    this->reg[SET][c] = fetch_buf(cg, ok, org[c] + t);
+                }
             } else {
 #pragma unroll
-                for (int c = 0; c < CPT; ++c) this->reg[SET][c] = zero_chunk<T>();
+                for (int c = 0; c < CPT; ++c)
+                    this->reg[SET][c] = live ? fetch(cg, pb[c], pd[c] + d, ph[c] + h, pw[c] + w, cc) : zero_chunk<T>();
             }
         } else {
 #pragma unroll
             for (int rr = 0; rr < RPT; ++rr) {
                 int d0, h0, w0, b0;
-                rows_of(cg, k0 + km_row(tid, rr * NG), d0, h0, w0, b0);
+                uint32_t origin;
+                rows_of(cg, k0 + km_row(tid, rr * NG), d0, h0, w0, b0, origin);
 #pragma unroll
-                for (int gidx = 0; gidx < NG; ++gidx)
-                    this->reg[SET][rr * NG + gidx] =
-                        kd[gidx] < 0 ? zero_chunk<T>() : fetch(cg, b0, d0 + kd[gidx], h0 + kh[gidx], w0 + kw[gidx], kc[gidx]);
+                for (int gidx = 0; gidx < NG; ++gidx) {
+                    if constexpr (BUF)
+                        this->reg[SET][rr * NG + gidx] = fetch_buf(cg, in_volume(cg, d0 + kd[gidx], h0 + kh[gidx], w0 + kw[gidx]), origin + ktap[gidx]);
+                    else
+                        this->reg[SET][rr * NG + gidx] = fetch(cg, b0, d0 + kd[gidx], h0 + kh[gidx], w0 + kw[gidx], kc[gidx]);
+                }
             }
         }
     }
@@ -253,9 +304,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
     constexpr int NS = NSplit<TI>::value;
     constexpr int BK = sizeof(TI) == 2 ? 64 : 32;
     constexpr int kBM = Cfg::BM, kBN = Cfg::BN, MI = Cfg::MI, NI = Cfg::NI;
-    static_assert(GATHER == 0 || (GATHER == 1 && !AKM && !BKM) || (GATHER == 2 && AKM && BKM), "gather variants: forward / dW layouts only");
-    using TA = std::conditional_t<GATHER == 1, GatherTile<TI, BK, false, kBM>, OperandTile<TI, BK, AKM, kBM>>;
-    using TB = std::conditional_t<GATHER == 2, GatherTile<TI, BK, true, kBN>, OperandTile<TI, BK, BKM, kBN>>;
+    constexpr bool GA = GATHER == 1 || GATHER == 3, GB = GATHER == 2 || GATHER == 4, GBUF = GATHER == 1 || GATHER == 2;
+    static_assert(GATHER == 0 || (GA && !AKM && !BKM) || (GB && AKM && BKM), "gather variants: forward / dW layouts only");
+    using TA = std::conditional_t<GA, GatherTile<TI, BK, false, kBM, GBUF>, OperandTile<TI, BK, AKM, kBM>>;
+    using TB = std::conditional_t<GB, GatherTile<TI, BK, true, kBN, GBUF>, OperandTile<TI, BK, BKM, kBN>>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16* lds = reinterpret_cast<bf16*>(smem);
     constexpr int A_SZ = NS * TA::IMG, B_SZ = NS * TB::IMG;
@@ -301,19 +353,19 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
     // set - a load has two compute phases to arrive, which matters at the blocks' K = 256 (4 tiles).
     auto issue_a = [&](auto set_tag, int kt) {
         constexpr int set = decltype(set_tag)::value;
-        if constexpr (GATHER == 1) ta.template issue<set>(g.cg, (int64_t)kt * BK, tid);
+        if constexpr (GA) ta.template issue<set>(g.cg, (int64_t)kt * BK, tid);
         else ta.template issue<set>(Ap, g.lda, i0, g.M, kt * BK, g.K, g.vec_a != 0, tid);
     };
     auto issue_b = [&](auto set_tag, int kt) {
         constexpr int set = decltype(set_tag)::value;
-        if constexpr (GATHER == 2) tb.template issue<set>(g.cg, (int64_t)kt * BK, tid);
+        if constexpr (GB) tb.template issue<set>(g.cg, (int64_t)kt * BK, tid);
         else tb.template issue<set>(Bp, g.ldb, j0, g.N, kt * BK, g.K, g.vec_b != 0, tid);
     };
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, 1>;
-    if constexpr (GATHER == 1) ta.init(g.cg, i0, tid);
+    if constexpr (GA) ta.init(g.cg, i0, tid);
     else ta.init(Ap, g.lda, i0, kt_begin * BK, tid);
-    if constexpr (GATHER == 2) tb.init(g.cg, j0, tid);
+    if constexpr (GB) tb.init(g.cg, j0, tid);
     else tb.init(Bp, g.ldb, j0, kt_begin * BK, tid);
     issue_a(S0{}, kt_begin);
     issue_b(S0{}, kt_begin);
@@ -532,7 +584,8 @@ hipError_t launch(const GemmArgs& g_in, hipStream_t st) {
     g.splitk = 1;
     const bool plain = !g.bias && g.act == kActNone && !g.aux && !g.zsave && !g.gate && !g.residual && !g.drop_thresh;
     if (plain && g.workspace && tiles <= 128 && nkt >= 8) {
-        int want = (512 + tiles - 1) / tiles;
+        int want = 512 / tiles;                      // tiles * slices <= 512 = one resident round (2 workgroups on each of 256 CUs);
+                                                     // rounding UP put e.g. 14 x 37 = 518 workgroups on the chip: two rounds, the second nearly empty
         if (want > nkt / 4) want = nkt / 4;          // >= 4 k-tiles per slice: slab traffic stays below the operand traffic
         const int64_t fit = g.workspace_floats / ((int64_t)g.M * g.N);
         if (want > fit) want = (int)fit;
@@ -571,10 +624,14 @@ hipError_t launch_layout(const GemmArgs& g, hipStream_t st) {
     }
     if (g.gather == 2) {
         if (!g.a_kmajor || !g.b_kmajor) return hipErrorInvalidValue;
-        if (g.M <= 32) return launch<TI, TO, true, true, 2, TileM32>(g, st);
-        if (g.M <= 64) return launch<TI, TO, true, true, 2, TileM64>(g, st);
+        const bool wide = g.N >= 1024;
+        if (g.M <= 32) return wide ? launch<TI, TO, true, true, 2, TileM32W>(g, st) : launch<TI, TO, true, true, 2, TileM32>(g, st);
+        if (g.M <= 64) return wide ? launch<TI, TO, true, true, 2, TileM64W>(g, st) : launch<TI, TO, true, true, 2, TileM64>(g, st);
         return launch<TI, TO, true, true, 2>(g, st);
     }
+    // activation tensors of 4 GiB and more: 64-bit addressed gather, 128 x 128 tiles only
+    if (g.gather == 3) return (g.a_kmajor || g.b_kmajor) ? hipErrorInvalidValue : launch<TI, TO, false, false, 3>(g, st);
+    if (g.gather == 4) return (!g.a_kmajor || !g.b_kmajor) ? hipErrorInvalidValue : launch<TI, TO, true, true, 4>(g, st);
     // Shapes that give the 512 workgroup slots of the chip fewer than ~3/4 of a round of 128 x 128 tiles (the 64^3 model's
     // token matrices: 16384 x 256 = 256 tiles) run on 64 x 128 tiles: twice the workgroups on the same latency chain.
     if (use_half_tile(g)) {

@@ -126,12 +126,12 @@ __device__ __forceinline__ int tile_off(int row, int chunk) {   // offset in bf1
     //  * ds_read_b64_tr_b16: the 4 consecutive rows x 4 consecutive chunks a 32-lane half touches
     //    must land on 16 distinct slots as well.
     int sw;
-    if constexpr (CW == 128) {          // 256-byte rows: every row starts on bank 0
+    if constexpr (CW == 128 || CW == 256) {   // 256 / 512-byte rows: every row starts on bank 0
         sw = chunk ^ (((row & 3) << 2) | ((row >> 2) & 3));
     } else if constexpr (CW == 64) {    // 128-byte rows: 2 rows per bank row
         sw = chunk ^ ((((row >> 1) & 1) << 2) | ((row >> 2) & 3));
     } else {                            // 64-byte rows: 4 rows per bank row
-        static_assert(CW == 32, "tile width must be 32, 64 or 128 bf16");
+        static_assert(CW == 32, "tile width must be 32, 64, 128 or 256 bf16");
         sw = chunk ^ ((row >> 2) & 3);
     }
     return row * CW + sw * 8;

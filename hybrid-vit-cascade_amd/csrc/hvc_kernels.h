@@ -62,6 +62,7 @@ struct ConvGather {
     int flip;               // taps run backwards (the stride-1 input gradient gathers dy with the mirrored kernel)
     int64_t M;              // B * OD * OH * OW patch rows
     int K;                  // KD * KH * KW * C patch columns
+    uint32_t bytes;         // size of the activation tensor when it is below 4 GiB (buffer-addressed gather), else 0
     FastDiv dC, dKW, dKH, dOW, dOH, dOD;
 };
 
@@ -93,7 +94,8 @@ struct GemmArgs {
     int64_t workspace_floats;
     int splitk;              // filled in by the launcher
     int gather;              // 0: both operands in memory; 1: A = conv patches (k-contiguous view), A / lda unused;
-                             // 2: B = conv patches (k-major view: contraction over patch rows), B / ldb unused
+                             // 2: B = conv patches (k-major view: contraction over patch rows), B / ldb unused;
+                             // 3 / 4: as 1 / 2 for activation tensors of 4 GiB and more (64-bit addressing)
     ConvGather cg;
 };
 int64_t gemm_workspace_floats(int M, int N, int K);

@@ -424,7 +424,7 @@ def conv_gemm_dw(x, dy2d, geom):
     N = dy2d.shape[1]
     out = torch.empty((N, K), dtype=torch.float32, device=x.device)
     lib = _lib.load()
-    ws, ws_n = None, lib.hvc_gemm_workspace(N, K, geom.M)
+    ws, ws_n = None, 2 * lib.hvc_gemm_workspace(N, K, geom.M)     # the flat 256-column tiles run up to twice the slices of 128-column ones
     if ws_n > 0:
         ws = torch.empty((ws_n,), dtype=torch.float32, device=x.device)
     return _conv_gemm_call(1, x, dy2d, out, geom, False, N, None, None, 0, ws, max(ws_n, 0), 2.0 * geom.M * N * K)
