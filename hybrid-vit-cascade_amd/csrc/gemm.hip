@@ -120,6 +120,13 @@ struct OperandTile {
         }
         next += kstep;
     }
+    // interior tile, decided once per workgroup: no condition at all around the loads (see the k loop)
+    template <int SET>
+    __device__ __forceinline__ void issue_fast() {
+#pragma unroll
+        for (int c = 0; c < CPT; ++c) reg[SET][c] = load_chunk<T>(next + c * rstep, 8, true);
+        next += kstep;
+    }
     template <int SET>
     __device__ __forceinline__ void commit(bf16* images, int tid) {
 #pragma unroll
@@ -351,31 +358,27 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
     // Software pipeline, two k-tiles deep: while tile kt is multiplied out of LDS buffer kt & 1, tile kt+1 sits in one
     // register set (written to the other LDS buffer at the end of the step) and tile kt+2 is in flight into the other
     // set - a load has two compute phases to arrive, which matters at the blocks' K = 256 (4 tiles).
-    auto issue_a = [&](auto set_tag, int kt) {
+    // FAST = the workgroup's tile is interior in both operands and every k-tile of its slice is full: the loads carry no
+    // condition.  This matters beyond the saved compares: any branch around a load - even a uniform one - leaves hipcc unable
+    // to count the loads in flight at the join, and it then waits for ALL of them (vmcnt(0)) before the LDS commit, i.e. also
+    // for the tile requested in this very step; the two-deep prefetch degrades to one.  So the decision is taken once, outside
+    // the k loop, and the bulk of the loop (every step that both requests and commits a tile) has no branch in it either.
+    auto issue_a = [&](auto set_tag, auto fast_tag, int kt) {
         constexpr int set = decltype(set_tag)::value;
         if constexpr (GA) ta.template issue<set>(g.cg, (int64_t)kt * BK, tid);
+        else if constexpr (decltype(fast_tag)::value) ta.template issue_fast<set>();
         else ta.template issue<set>(Ap, g.lda, i0, g.M, kt * BK, g.K, g.vec_a != 0, tid);
     };
-    auto issue_b = [&](auto set_tag, int kt) {
+    auto issue_b = [&](auto set_tag, auto fast_tag, int kt) {
         constexpr int set = decltype(set_tag)::value;
         if constexpr (GB) tb.template issue<set>(g.cg, (int64_t)kt * BK, tid);
+        else if constexpr (decltype(fast_tag)::value) tb.template issue_fast<set>();
         else tb.template issue<set>(Bp, g.ldb, j0, g.N, kt * BK, g.K, g.vec_b != 0, tid);
     };
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, 1>;
-    if constexpr (GA) ta.init(g.cg, i0, tid);
-    else ta.init(Ap, g.lda, i0, kt_begin * BK, tid);
-    if constexpr (GB) tb.init(g.cg, j0, tid);
-    else tb.init(Bp, g.ldb, j0, kt_begin * BK, tid);
-    issue_a(S0{}, kt_begin);
-    issue_b(S0{}, kt_begin);
-    if (kt_begin + 1 < kt_end) {
-        issue_a(S1{}, kt_begin + 1);
-        issue_b(S1{}, kt_begin + 1);
-    }
-    ta.template commit<0>(At(0), tid);
-    tb.template commit<0>(Bt(0), tid);
-    __syncthreads();
+    const bool k_full = (int64_t)kt_end * BK <= g.K;
+    const bool all_fast = kt_begin < kt_end && k_full && (GA || (TA::FULL && g.vec_a != 0 && i0 + kBM <= g.M)) && (GB || (TB::FULL && g.vec_b != 0 && j0 + kBN <= g.N));
 
     f32x16 acc[MI][NI];
 #pragma unroll
@@ -385,12 +388,29 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[mi][ni][i] = 0.f;
 
+    auto run = [&](auto fast_tag) {
+    if constexpr (GA) ta.init(g.cg, i0, tid);
+    else ta.init(Ap, g.lda, i0, kt_begin * BK, tid);
+    if constexpr (GB) tb.init(g.cg, j0, tid);
+    else tb.init(Bp, g.ldb, j0, kt_begin * BK, tid);
+    issue_a(S0{}, fast_tag, kt_begin);
+    issue_b(S0{}, fast_tag, kt_begin);
+    if (kt_begin + 1 < kt_end) {
+        issue_a(S1{}, fast_tag, kt_begin + 1);
+        issue_b(S1{}, fast_tag, kt_begin + 1);
+    }
+    ta.template commit<0>(At(0), tid);
+    tb.template commit<0>(Bt(0), tid);
+    __syncthreads();
+
     // one k-step: BUF = LDS buffer holding tile kt; register set BUF ^ 1 holds tile kt+1; tile kt+2 goes to set BUF.
-    auto kstep = [&](auto buf_tag, int kt) {
+    // BULK: kt + 2 < kt_end is known to the caller (request and commit unconditionally).
+    auto kstep = [&](auto buf_tag, auto bulk_tag, int kt) {
         constexpr int buf = decltype(buf_tag)::value;
-        if (kt + 2 < kt_end) {
-            issue_a(buf_tag, kt + 2);
-            issue_b(buf_tag, kt + 2);
+        constexpr bool BULK = decltype(bulk_tag)::value;
+        if (BULK || kt + 2 < kt_end) {
+            issue_a(buf_tag, fast_tag, kt + 2);
+            issue_b(buf_tag, fast_tag, kt + 2);
         }
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
@@ -412,7 +432,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
                         for (int sb = 0; sb < NS; ++sb)
                             if (sa + sb <= 1) acc[mi][ni] = mfma32(af[sa][mi], bfr[sb][ni], acc[mi][ni]);
         }
-        if (kt + 1 < kt_end) {
+        if (BULK || kt + 1 < kt_end) {
             ta.template commit<buf ^ 1>(At(buf ^ 1), tid);
             tb.template commit<buf ^ 1>(Bt(buf ^ 1), tid);
         }
@@ -420,12 +440,19 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
     };
     {
         int kt = kt_begin;
-        for (; kt + 1 < kt_end; kt += 2) {
-            kstep(S0{}, kt);
-            kstep(S1{}, kt + 1);
+        for (; kt + 3 < kt_end; kt += 2) {         // both steps request a tile: no branch in this loop body
+            kstep(S0{}, std::true_type{}, kt);
+            kstep(S1{}, std::true_type{}, kt + 1);
         }
-        if (kt < kt_end) kstep(S0{}, kt);
+        for (; kt + 1 < kt_end; kt += 2) {
+            kstep(S0{}, std::false_type{}, kt);
+            kstep(S1{}, std::false_type{}, kt + 1);
+        }
+        if (kt < kt_end) kstep(S0{}, std::false_type{}, kt);
     }
+    };
+    if (all_fast) run(std::true_type{});
+    else run(std::false_type{});
 
     // ---- epilogue: stage the 128 x 128 fp32 tile through LDS (the operand buffers are free now) so that
     // every global access of the epilogue is a 16/32-byte row segment instead of a 2/4-byte column element.
@@ -589,7 +616,10 @@ hipError_t launch(const GemmArgs& g_in, hipStream_t st) {
         if (want > nkt / 4) want = nkt / 4;          // >= 4 k-tiles per slice: slab traffic stays below the operand traffic
         const int64_t fit = g.workspace_floats / ((int64_t)g.M * g.N);
         if (want > fit) want = (int)fit;
-        if (want >= 2) g.splitk = want;
+        if (want >= 2) {
+            const int per_split = (nkt + want - 1) / want;
+            g.splitk = (nkt + per_split - 1) / per_split;      // no empty trailing slice (the kernel derives the same per-slice count)
+        }
     }
     hipLaunchKernelGGL(k, dim3(tiles * g.splitk), dim3(256), lds, st, g);
     hipError_t e = hipGetLastError();

@@ -480,6 +480,26 @@ def test_gemm_layouts_and_ragged_shapes(M, N, K, akm, bkm, dtype):
     assert ((C.cpu().double() - ref).abs().max() / (ref.abs().max() + 1e-12)).item() < tol
 
 
+@pytest.mark.parametrize("M,N,K", [(768, 256, 65536), (256, 3456, 16384), (384, 200, 16448), (128, 128, 640), (1024, 256, 4100), (64, 1728, 40000)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemm_splitk_weight_gradient_shapes(M, N, K, dtype):
+    """dW = dy^T x (both operands k-major, fp32 out) on shapes whose split-K slicing is uneven: tile counts that do not divide the
+    512 resident workgroup slots (768 x 256: 12 tiles -> 42 slices of 25 k-tiles would leave an EMPTY 42nd slice - the launcher
+    trims it; an unguarded fast path once read beyond K there), ragged K, ragged N, and the few-row tiles.  Twice: bit-equal
+    (the slice order is fixed)."""
+    from hvc import ops
+    g = torch.Generator().manual_seed(M + 3 * N + K)
+    A = torch.randn(K, M, generator=g).to(dtype)
+    Bm = torch.randn(K, N, generator=g).to(dtype)
+    ref = A.double().t() @ Bm.double()
+    a_in, b_in = A.to(dev()), Bm.to(dev())
+    C1 = ops.gemm(a_in, b_in, a_kmajor=True, b_kmajor=True, out_dtype=torch.float32)
+    C2 = ops.gemm(a_in, b_in, a_kmajor=True, b_kmajor=True, out_dtype=torch.float32)
+    assert torch.equal(C1, C2)
+    tol = 1e-4 if dtype == torch.float32 else 3e-3
+    assert ((C1.cpu().double() - ref).abs().max() / (ref.abs().max() + 1e-12)).item() < tol
+
+
 @pytest.mark.parametrize("M,N,K", [(2, 1536, 1024), (1, 7, 260), (8, 130, 512), (4, 512, 256)])
 def test_gemm_few_rows_fp32_conditioning_linears(M, N, K):
     """M <= 8 fp32 rows (AdaLNModulation.linear, vit_components.py:131-147; time / context MLPs of diagnostic_losses.py:99-103,
