@@ -1245,6 +1245,35 @@ def test_conv_implicit_gemm_vs_fp64_and_im2col(cfg, dtype):
     assert torch.equal(results["implicit"][0], results["im2col"][0])
 
 
+def test_conv_gemm_rejects_what_it_cannot_gather():
+    """hvc_conv_gemm error behaviour: channel counts that are not a multiple of 8 (the gather moves 16-byte channel vectors; such
+    layers stay on im2col), a wrong weight shape, a wrong activation shape and depth-slab geometries raise instead of computing."""
+    from hvc import ops
+    x = torch.randn(1, 4, 5, 6, 12, device=dev(), dtype=torch.bfloat16)
+    w = torch.randn(8, 27 * 12, device=dev(), dtype=torch.bfloat16)
+    geom = ops.ConvGeometry(1, 12, (4, 5, 6), (3, 3, 3), 1, (1, 1, 1))
+    with pytest.raises(ValueError, match="C % 8"):
+        ops.conv_gemm(x, w, geom)
+    x16 = torch.randn(1, 4, 5, 6, 16, device=dev(), dtype=torch.bfloat16)
+    g16 = ops.ConvGeometry(1, 16, (4, 5, 6), (3, 3, 3), 1, (1, 1, 1))
+    with pytest.raises(ValueError, match="weights"):
+        ops.conv_gemm(x16, w, g16)
+    with pytest.raises(ValueError, match="channels-last"):
+        ops.conv_gemm(x16[:, :3], torch.randn(8, 27 * 16, device=dev(), dtype=torch.bfloat16), g16)
+    slab = ops.ConvGeometry(1, 16, (4, 5, 6), (3, 3, 3), 1, (1, 1, 1), out_depth=2)
+    with pytest.raises(ValueError, match="slab"):
+        ops.conv_gemm(x16, torch.randn(8, 27 * 16, device=dev(), dtype=torch.bfloat16), slab)
+    from hvc import _lib
+    lib = _lib.load()                                     # and the C ABI itself, behind the Python checks
+    y = torch.empty(120, 8, device=dev(), dtype=torch.bfloat16)
+    rc = lib.hvc_conv_gemm(0, x.data_ptr(), w.data_ptr(), y.data_ptr(), 1, 12, 4, 5, 6, 3, 3, 3, 1, 1, 1, 1, 0, 8, 27 * 12, 8,
+                           None, None, 0, 0, None, 0, 1, 1, None)
+    assert rc != 0 and b"C % 8" in lib.hvc_last_error()
+    rc = lib.hvc_conv_gemm(7, x16.data_ptr(), w.data_ptr(), y.data_ptr(), 1, 16, 4, 5, 6, 3, 3, 3, 1, 1, 1, 1, 0, 8, 27 * 16, 8,
+                           None, None, 0, 0, None, 0, 1, 1, None)
+    assert rc != 0 and b"mode" in lib.hvc_last_error()
+
+
 @pytest.mark.parametrize("seed", range(8))
 def test_ssim_l1_loss_random_sizes_and_weights(seed):
     """DirectRegressionLoss (model_direct.py:69-133) at random non-cubic volume sizes from the 11-voxel window upwards, random
