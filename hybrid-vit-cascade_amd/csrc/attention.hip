@@ -433,33 +433,45 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const AttnArgs a_in) 
     const T* knext = kp + (int64_t)lrow * a.k_sn + lch * 8;
     const T* vnext = vp + (int64_t)lrow * a.v_sn + lch * 8;
     const int64_t kstep = (int64_t)kKT2 * a.k_sn, vstep = (int64_t)kKT2 * a.v_sn;
-    Chunk8<T> kreg, vreg;
-    auto issue = [&](int row0) {
-        if (lactive) {
+    // Two register sets: tile t+2 is requested at the start of tile t and tile t+1 (requested a tile earlier) is written to LDS
+    // at its end - a load has two tiles to arrive.  FAST (every thread loads, the tile is full): no condition around the loads;
+    // the bulk of the sweep uses only that form, so hipcc can count the loads in flight and waits for the older pair alone.
+    constexpr bool CAN_FAST = kKT2 * CPR == 256;
+    Chunk8<T> kreg[2], vreg[2];
+    auto issue = [&](auto set_tag, auto fast_tag, int row0) {
+        constexpr int set = decltype(set_tag)::value;
+        if constexpr (decltype(fast_tag)::value) {
+            kreg[set] = load_chunk<T>(knext, 8, true);
+            vreg[set] = load_chunk<T>(vnext, 8, true);
+        } else if (lactive) {
             if (row0 + kKT2 <= a.Nk) {
-                kreg = load_chunk<T>(knext, 8, true);
-                vreg = load_chunk<T>(vnext, 8, true);
+                kreg[set] = load_chunk<T>(knext, 8, true);
+                vreg[set] = load_chunk<T>(vnext, 8, true);
             } else {
-                kreg = load_row_chunk<T, true>(kp, a.k_sn, row0 + lrow, a.Nk, lch * 8);
-                vreg = load_row_chunk<T, true>(vp, a.v_sn, row0 + lrow, a.Nk, lch * 8);
+                kreg[set] = load_row_chunk<T, true>(kp, a.k_sn, row0 + lrow, a.Nk, lch * 8);
+                vreg[set] = load_row_chunk<T, true>(vp, a.v_sn, row0 + lrow, a.Nk, lch * 8);
             }
         }
         knext += kstep;
         vnext += vstep;
     };
-    auto commit = [&](int buf) {
-        if (lactive) {
+    auto commit = [&](auto set_tag, int buf) {
+        constexpr int set = decltype(set_tag)::value;
+        if (CAN_FAST || lactive) {
             bf16x8 im[1];
-            chunk_split<T>(kreg, im);
+            chunk_split<T>(kreg[set], im);
             tile_store<D>(lds + (buf * 2 + 0) * TILE, lrow, lch, im[0]);
-            chunk_split<T>(vreg, im);
+            chunk_split<T>(vreg[set], im);
             tile_store<D>(lds + (buf * 2 + 1) * TILE, lrow, lch, im[0]);
         }
     };
+    using B0 = std::integral_constant<int, 0>;
+    using B1 = std::integral_constant<int, 1>;
 
     const int nt = (a.Nk + kKT2 - 1) / kKT2;
-    issue(0);
-    commit(0);
+    issue(B0{}, std::false_type{}, 0);
+    commit(B0{}, 0);
+    if (nt > 1) issue(B1{}, std::false_type{}, kKT2);
     __syncthreads();
 
     float l[2] = {0.f, 0.f};
@@ -485,11 +497,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const AttnArgs a_in) 
         vaddr[dt][1] = lds + ob;
     }
 
-    auto tile = [&](auto mask_tag, auto buf_tag, int t) {
+    auto tile = [&](auto mask_tag, auto buf_tag, auto bulk_tag, int t) {
         constexpr bool MASK = decltype(mask_tag)::value;
         constexpr int buf = decltype(buf_tag)::value;            // = t & 1 = which half of the 64-key hash tile
+        constexpr bool BULK = decltype(bulk_tag)::value;         // tile t+2 exists and is full (the caller knows)
         constexpr int KOFF = (buf * 2 + 0) * TILE, VOFF = (buf * 2 + 1) * TILE;
-        if (t + 1 < nt) issue((t + 1) * kKT2);
+        if (BULK || t + 2 < nt) issue(buf_tag, bulk_tag, (t + 2) * kKT2);
         f32x16 st[2];
         auto scores = [&]() {                                     // S^T = K Q^T in exp2 units, minus the reference exponent
             st[0] = negm[0];
@@ -609,22 +622,26 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const AttnArgs a_in) 
                 for (int dt = 0; dt < D / 32; ++dt) o[blk][dt] = mfma32(vfr[dt], pf[0], o[blk][dt]);
             }
         }
-        if (t + 1 < nt) commit(buf ^ 1);
+        if (BULK || t + 1 < nt) commit(std::integral_constant<int, buf ^ 1>{}, buf ^ 1);
         __syncthreads();
     };
     const bool ragged = (a.Nk % kKT2) != 0;
     const int nfull = ragged ? nt - 1 : nt;
-    using B0 = std::integral_constant<int, 0>;
-    using B1 = std::integral_constant<int, 1>;
     int t = 0;
-    for (; t + 1 < nfull; t += 2) {
-        tile(std::false_type{}, B0{}, t);
-        tile(std::false_type{}, B1{}, t + 1);
+    if constexpr (CAN_FAST) {
+        for (; t + 3 < nfull; t += 2) {                         // tiles t+2 and t+3 are full: branch-free requests
+            tile(std::false_type{}, B0{}, std::true_type{}, t);
+            tile(std::false_type{}, B1{}, std::true_type{}, t + 1);
+        }
     }
-    if (t < nfull) tile(std::false_type{}, B0{}, t);            // t is even here
+    for (; t + 1 < nfull; t += 2) {
+        tile(std::false_type{}, B0{}, std::false_type{}, t);
+        tile(std::false_type{}, B1{}, std::false_type{}, t + 1);
+    }
+    if (t < nfull) tile(std::false_type{}, B0{}, std::false_type{}, t);            // t is even here
     if (ragged) {
-        if ((nt - 1) & 1) tile(std::true_type{}, B1{}, nt - 1);
-        else tile(std::true_type{}, B0{}, nt - 1);
+        if ((nt - 1) & 1) tile(std::true_type{}, B1{}, std::false_type{}, nt - 1);
+        else tile(std::true_type{}, B0{}, std::false_type{}, nt - 1);
     }
 
 #pragma unroll
