@@ -427,40 +427,41 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const AttnArgs a_in) 
     }
     const uint32_t tm1x2 = DROP ? ((uint32_t)(drop_ts(a) - 1) & 0xffffu) * 0x10001u : 0u;
 
-    // tile loader: one 16-byte chunk of K and of V per thread (D = 32: the first 128 threads)
-    const int lrow = tid / CPR, lch = tid % CPR;
-    const bool lactive = lrow < kKT2;
-    const T* knext = kp + (int64_t)lrow * a.k_sn + lch * 8;
-    const T* vnext = vp + (int64_t)lrow * a.v_sn + lch * 8;
-    const int64_t kstep = (int64_t)kKT2 * a.k_sn, vstep = (int64_t)kKT2 * a.v_sn;
+    // tile loader: a 32-key tile is 32 * D / 8 chunks of 16 bytes per operand.  D = 64: 256 chunks, every thread loads one of K
+    // and one of V.  D = 32: 128 chunks, threads 0..127 load K, threads 128..255 load V - every thread has exactly one load,
+    // so neither case needs a condition around it.
     // Two register sets: tile t+2 is requested at the start of tile t and tile t+1 (requested a tile earlier) is written to LDS
-    // at its end - a load has two tiles to arrive.  FAST (every thread loads, the tile is full): no condition around the loads;
-    // the bulk of the sweep uses only that form, so hipcc can count the loads in flight and waits for the older pair alone.
-    constexpr bool CAN_FAST = kKT2 * CPR == 256;
+    // at its end - a load has two tiles to arrive.  FAST (the tile is full): no condition around the loads; the bulk of the
+    // sweep uses only that form, so hipcc can count the loads in flight and waits for the older tile alone.
+    constexpr bool HALF = kKT2 * CPR == 128;
+    static_assert(HALF || kKT2 * CPR == 256, "one or two chunks per thread");
+    const int ltid = HALF ? (tid & 127) : tid;
+    const bool isv = HALF && tid >= 128;
+    const int lrow = ltid / CPR, lch = ltid % CPR;
+    const T* xbase = isv ? vp : kp;                      // HALF: this thread's operand
+    const int64_t xsn = isv ? a.v_sn : a.k_sn;
+    const T* knext = xbase + (int64_t)lrow * xsn + lch * 8;
+    const T* vnext = vp + (int64_t)lrow * a.v_sn + lch * 8;
+    const int64_t kstep = (int64_t)kKT2 * xsn, vstep = (int64_t)kKT2 * a.v_sn;
     Chunk8<T> kreg[2], vreg[2];
     auto issue = [&](auto set_tag, auto fast_tag, int row0) {
         constexpr int set = decltype(set_tag)::value;
-        if constexpr (decltype(fast_tag)::value) {
+        if (decltype(fast_tag)::value || row0 + kKT2 <= a.Nk) {
             kreg[set] = load_chunk<T>(knext, 8, true);
-            vreg[set] = load_chunk<T>(vnext, 8, true);
-        } else if (lactive) {
-            if (row0 + kKT2 <= a.Nk) {
-                kreg[set] = load_chunk<T>(knext, 8, true);
-                vreg[set] = load_chunk<T>(vnext, 8, true);
-            } else {
-                kreg[set] = load_row_chunk<T, true>(kp, a.k_sn, row0 + lrow, a.Nk, lch * 8);
-                vreg[set] = load_row_chunk<T, true>(vp, a.v_sn, row0 + lrow, a.Nk, lch * 8);
-            }
+            if constexpr (!HALF) vreg[set] = load_chunk<T>(vnext, 8, true);
+        } else {
+            kreg[set] = load_row_chunk<T, true>(xbase, xsn, row0 + lrow, a.Nk, lch * 8);
+            if constexpr (!HALF) vreg[set] = load_row_chunk<T, true>(vp, a.v_sn, row0 + lrow, a.Nk, lch * 8);
         }
         knext += kstep;
         vnext += vstep;
     };
     auto commit = [&](auto set_tag, int buf) {
         constexpr int set = decltype(set_tag)::value;
-        if (CAN_FAST || lactive) {
-            bf16x8 im[1];
-            chunk_split<T>(kreg[set], im);
-            tile_store<D>(lds + (buf * 2 + 0) * TILE, lrow, lch, im[0]);
+        bf16x8 im[1];
+        chunk_split<T>(kreg[set], im);
+        tile_store<D>(lds + (buf * 2 + (isv ? 1 : 0)) * TILE, lrow, lch, im[0]);
+        if constexpr (!HALF) {
             chunk_split<T>(vreg[set], im);
             tile_store<D>(lds + (buf * 2 + 1) * TILE, lrow, lch, im[0]);
         }
@@ -628,11 +629,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const AttnArgs a_in) 
     const bool ragged = (a.Nk % kKT2) != 0;
     const int nfull = ragged ? nt - 1 : nt;
     int t = 0;
-    if constexpr (CAN_FAST) {
-        for (; t + 3 < nfull; t += 2) {                         // tiles t+2 and t+3 are full: branch-free requests
-            tile(std::false_type{}, B0{}, std::true_type{}, t);
-            tile(std::false_type{}, B1{}, std::true_type{}, t + 1);
-        }
+    for (; t + 3 < nfull; t += 2) {                             // tiles t+2 and t+3 are full: branch-free requests
+        tile(std::false_type{}, B0{}, std::true_type{}, t);
+        tile(std::false_type{}, B1{}, std::true_type{}, t + 1);
     }
     for (; t + 1 < nfull; t += 2) {
         tile(std::false_type{}, B0{}, std::false_type{}, t);
