@@ -32,6 +32,61 @@ __global__ __launch_bounds__(256) void ssim_pass_w_kernel(const float* __restric
     }
 }
 
+// The two W-axis passes for the 11-voxel window and W % 4 == 0: a thread produces 4 consecutive outputs from five aligned
+// 16-byte loads per input row (20 values, 14 used) instead of 44 scalar loads; every output is still the ascending sum over
+// its window with exact zeros outside the row (bit-identical to the scalar kernels below).
+__device__ __forceinline__ void load_w20(const float* row, int w0, int W, float (&v)[20]) {
+#pragma unroll
+    for (int c = 0; c < 5; ++c) {
+        const int x0 = w0 - 8 + 4 * c;
+        f32x4 q = {0.f, 0.f, 0.f, 0.f};
+        if (x0 >= 0 && x0 < W) q = *reinterpret_cast<const f32x4*>(row + x0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[4 * c + e] = q[e];
+    }
+}
+__global__ __launch_bounds__(256) void ssim_pass_w4_kernel(const float* __restrict__ p, const float* __restrict__ t, float* __restrict__ out,
+                                                            int64_t rows, int W) {
+    const int wq = W / 4;
+    const int64_t total = rows * W, total4 = rows * wq;
+    for (int64_t i4 = (int64_t)blockIdx.x * 256 + threadIdx.x; i4 < total4; i4 += (int64_t)gridDim.x * 256) {
+        const int w0 = (int)(i4 % wq) * 4;
+        const int64_t base = (i4 / wq) * W;
+        float a[20], b[20];
+        load_w20(p + base, w0, W, a);
+        load_w20(t + base, w0, W, b);
+        f32x4 o[5];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0;
+#pragma unroll
+            for (int k = j + 3; k <= j + 13; ++k) { s0 += a[k]; s1 += b[k]; s2 += a[k] * a[k]; s3 += b[k] * b[k]; s4 += a[k] * b[k]; }
+            o[0][j] = s0; o[1][j] = s1; o[2][j] = s2; o[3][j] = s3; o[4][j] = s4;
+        }
+#pragma unroll
+        for (int q = 0; q < 5; ++q) *reinterpret_cast<f32x4*>(out + q * total + base + w0) = o[q];
+    }
+}
+__global__ __launch_bounds__(256) void box_w4_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t rows, int W) {
+    const int wq = W / 4;
+    const int64_t total4 = rows * wq;
+    for (int64_t i4 = (int64_t)blockIdx.x * 256 + threadIdx.x; i4 < total4; i4 += (int64_t)gridDim.x * 256) {
+        const int w0 = (int)(i4 % wq) * 4;
+        const int64_t base = (i4 / wq) * W;
+        float a[20];
+        load_w20(in + base, w0, W, a);
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float s0 = 0;
+#pragma unroll
+            for (int k = j + 3; k <= j + 13; ++k) s0 += a[k];
+            o[j] = s0;
+        }
+        *reinterpret_cast<f32x4*>(out + base + w0) = o;
+    }
+}
+
 // generic zero-padded box sum of nmaps volumes [n][L0][axis][inner] along `axis` (stride = inner)
 __global__ __launch_bounds__(256) void box_axis_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t total, int len, int64_t inner, int R) {
     for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
@@ -43,35 +98,96 @@ __global__ __launch_bounds__(256) void box_axis_kernel(const float* __restrict__
     }
 }
 
+// The same sum for a strided axis (inner > 1) with the usual 11-voxel window: a thread produces RUN consecutive outputs along
+// the axis from RUN + 2R loaded values instead of RUN * (2R + 1) - 2.25 loads per output instead of 11 (the cache served
+// the difference, at 1.5 TB/s of useful traffic).  Each output is still the ascending sum over its window with exact
+// zeros outside the volume, i.e. bit-identical to box_axis_kernel.
+template <int RUN, int R>
+__global__ __launch_bounds__(256) void box_axis_run_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t n_outer, int len, int64_t inner) {
+    const int nrun = (len + RUN - 1) / RUN;
+    const int64_t total = n_outer * nrun * inner;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int64_t i = idx % inner, t2 = idx / inner;
+        const int a0 = (int)(t2 % nrun) * RUN;
+        const int64_t base = (t2 / nrun) * len * inner + i;
+        float v[RUN + 2 * R];
+#pragma unroll
+        for (int k = 0; k < RUN + 2 * R; ++k) {
+            const int x = a0 - R + k;
+            v[k] = (x >= 0 && x < len) ? in[base + (int64_t)x * inner] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < RUN; ++j) {
+            if (a0 + j < len) {
+                float s = 0.f;
+#pragma unroll
+                for (int k = 0; k <= 2 * R; ++k) s += v[j + k];
+                out[base + (int64_t)(a0 + j) * inner] = s;
+            }
+        }
+    }
+}
+
 // last axis pass (along D) fused with the SSIM point function.
 // in: 5 maps box-summed along W and H; writes GA, GPP, GPT (3 maps) and block partials (sum S, sum |p - t|).
+template <int RUN, int RW>
 __global__ __launch_bounds__(256) void ssim_point_kernel(const float* __restrict__ in, const float* __restrict__ p, const float* __restrict__ t,
                                                           float* __restrict__ gmaps, float* __restrict__ partial,
                                                           int64_t nvox, int D, int64_t HW, int R, float inv_win) {
     __shared__ float red[2][4];
     const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
     float accS = 0.f, accL = 0.f;
-    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < nvox; idx += (int64_t)gridDim.x * 256) {
-        const int d = (int)((idx / HW) % D);
-        const int lo = max(0, d - R), hi = min(D - 1, d + R);
-        float m[5] = {0, 0, 0, 0, 0};
-        for (int x = lo; x <= hi; ++x) {
-            const int64_t o = idx + (int64_t)(x - d) * HW;
+    // A thread owns RUN consecutive depths of one (h, w) column: RUN + 2 RW planes of the 5 maps are loaded once and each voxel's
+    // window sum is the ascending sum over its 2 RW + 1 planes (exact zeros outside the volume): RW = 5 is the 11-voxel window,
+    // RUN = 1 / RW = 0 selects the generic per-voxel loop for any other window.
+    const int nrun = (D + RUN - 1) / RUN;
+    const int64_t nwork = (nvox / D) * nrun;             // (batch, run, h, w)
+    for (int64_t widx = (int64_t)blockIdx.x * 256 + threadIdx.x; widx < nwork; widx += (int64_t)gridDim.x * 256) {
+        const int64_t hw = widx % HW, t2 = widx / HW;
+        const int d0 = (int)(t2 % nrun) * RUN;
+        const int64_t base = (t2 / nrun) * D * HW + hw;
+        float v[5][RUN + 2 * RW];
+        if constexpr (RW > 0) {
 #pragma unroll
-            for (int q = 0; q < 5; ++q) m[q] += in[q * nvox + o];
+            for (int k = 0; k < RUN + 2 * RW; ++k) {
+                const int x = d0 - RW + k;
+                const bool ok = x >= 0 && x < D;
+#pragma unroll
+                for (int q = 0; q < 5; ++q) v[q][k] = ok ? in[q * nvox + base + (int64_t)x * HW] : 0.f;
+            }
         }
-        const float a = m[0] * inv_win, b = m[1] * inv_win, epp = m[2] * inv_win, ett = m[3] * inv_win, ept = m[4] * inv_win;
-        const float N1 = 2.f * a * b + C1, N2 = 2.f * (ept - a * b) + C2;
-        const float D1 = a * a + b * b + C1, D2 = (epp - a * a) + (ett - b * b) + C2;
-        // Derivatives are formed from dS/dN = N_other / (D1 D2), never by dividing S by a numerator: N2 (and N1)
-        // pass through zero for anti-correlated windows, where S / N2 would be 0/0.
-        const float inv = 1.f / (D1 * D2);
-        const float S = (N1 * N2) * inv;
-        gmaps[idx] = 2.f * b * (N2 - N1) * inv + 2.f * a * S * (1.f / D2 - 1.f / D1);   // dS/dmu_p
-        gmaps[nvox + idx] = -S / D2;                                                      // dS/dE[p^2]
-        gmaps[2 * nvox + idx] = 2.f * N1 * inv;                                           // dS/dE[pt]
-        accS += S;
-        accL += fabsf(p[idx] - t[idx]);
+#pragma unroll
+        for (int j = 0; j < RUN; ++j) {
+            const int d = d0 + j;
+            if (d >= D) break;
+            const int64_t idx = base + (int64_t)d * HW;
+            float m[5] = {0, 0, 0, 0, 0};
+            if constexpr (RW > 0) {
+#pragma unroll
+                for (int k = 0; k <= 2 * RW; ++k)
+#pragma unroll
+                    for (int q = 0; q < 5; ++q) m[q] += v[q][j + k];
+            } else {
+                const int lo = max(0, d - R), hi = min(D - 1, d + R);
+                for (int x = lo; x <= hi; ++x) {
+                    const int64_t o = idx + (int64_t)(x - d) * HW;
+#pragma unroll
+                    for (int q = 0; q < 5; ++q) m[q] += in[q * nvox + o];
+                }
+            }
+            const float a = m[0] * inv_win, b = m[1] * inv_win, epp = m[2] * inv_win, ett = m[3] * inv_win, ept = m[4] * inv_win;
+            const float N1 = 2.f * a * b + C1, N2 = 2.f * (ept - a * b) + C2;
+            const float D1 = a * a + b * b + C1, D2 = (epp - a * a) + (ett - b * b) + C2;
+            // Derivatives are formed from dS/dN = N_other / (D1 D2), never by dividing S by a numerator: N2 (and N1)
+            // pass through zero for anti-correlated windows, where S / N2 would be 0/0.
+            const float inv = 1.f / (D1 * D2);
+            const float S = (N1 * N2) * inv;
+            gmaps[idx] = 2.f * b * (N2 - N1) * inv + 2.f * a * S * (1.f / D2 - 1.f / D1);   // dS/dmu_p
+            gmaps[nvox + idx] = -S / D2;                                                      // dS/dE[p^2]
+            gmaps[2 * nvox + idx] = 2.f * N1 * inv;                                           // dS/dE[pt]
+            accS += S;
+            accL += fabsf(p[idx] - t[idx]);
+        }
     }
     accS = wave_sum(accS);
     accL = wave_sum(accL);
@@ -105,6 +221,7 @@ __global__ __launch_bounds__(256) void loss_finish_kernel(const float* __restric
 }
 
 // last backward axis pass (along D) fused with the combination into dpred
+template <int RUN, int RW>
 __global__ __launch_bounds__(256) void ssim_grad_kernel(const float* __restrict__ g /*3 maps filtered along W,H*/, const float* __restrict__ p,
                                                          const float* __restrict__ t, const float* __restrict__ gscale, float* __restrict__ dp,
                                                          int64_t nvox, int D, int64_t HW, int R, float inv_win, float l1_w, float ssim_w) {
@@ -112,19 +229,44 @@ __global__ __launch_bounds__(256) void ssim_grad_kernel(const float* __restrict_
     const float el1 = gscale ? gscale[0] * l1_w + gscale[1] : l1_w;
     const float ess = gscale ? gscale[0] * ssim_w + gscale[2] : ssim_w;
     const float inv_n = 1.f / (float)nvox;
-    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < nvox; idx += (int64_t)gridDim.x * 256) {
-        const int d = (int)((idx / HW) % D);
-        const int lo = max(0, d - R), hi = min(D - 1, d + R);
-        float m0 = 0, m1 = 0, m2 = 0;
-        for (int x = lo; x <= hi; ++x) {
-            const int64_t o = idx + (int64_t)(x - d) * HW;
-            m0 += g[o]; m1 += g[nvox + o]; m2 += g[2 * nvox + o];
+    const int nrun = (D + RUN - 1) / RUN;                // RUN consecutive depths per thread, as in ssim_point_kernel
+    const int64_t nwork = (nvox / D) * nrun;
+    for (int64_t widx = (int64_t)blockIdx.x * 256 + threadIdx.x; widx < nwork; widx += (int64_t)gridDim.x * 256) {
+        const int64_t hw = widx % HW, t2 = widx / HW;
+        const int d0 = (int)(t2 % nrun) * RUN;
+        const int64_t base = (t2 / nrun) * D * HW + hw;
+        float v[3][RUN + 2 * RW];
+        if constexpr (RW > 0) {
+#pragma unroll
+            for (int k = 0; k < RUN + 2 * RW; ++k) {
+                const int x = d0 - RW + k;
+                const bool ok = x >= 0 && x < D;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) v[q][k] = ok ? g[q * nvox + base + (int64_t)x * HW] : 0.f;
+            }
         }
-        const float pv = p[idx], tv = t[idx];
-        const float dS = (m0 + 2.f * pv * m1 + tv * m2) * inv_win;
-        const float diff = pv - tv;
-        const float sgn = diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f);
-        dp[idx] = inv_n * (el1 * sgn - ess * dS);
+#pragma unroll
+        for (int j = 0; j < RUN; ++j) {
+            const int d = d0 + j;
+            if (d >= D) break;
+            const int64_t idx = base + (int64_t)d * HW;
+            float m0 = 0, m1 = 0, m2 = 0;
+            if constexpr (RW > 0) {
+#pragma unroll
+                for (int k = 0; k <= 2 * RW; ++k) { m0 += v[0][j + k]; m1 += v[1][j + k]; m2 += v[2][j + k]; }
+            } else {
+                const int lo = max(0, d - R), hi = min(D - 1, d + R);
+                for (int x = lo; x <= hi; ++x) {
+                    const int64_t o = idx + (int64_t)(x - d) * HW;
+                    m0 += g[o]; m1 += g[nvox + o]; m2 += g[2 * nvox + o];
+                }
+            }
+            const float pv = p[idx], tv = t[idx];
+            const float dS = (m0 + 2.f * pv * m1 + tv * m2) * inv_win;
+            const float diff = pv - tv;
+            const float sgn = diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f);
+            dp[idx] = inv_n * (el1 * sgn - ess * dS);
+        }
     }
 }
 
@@ -133,6 +275,17 @@ int grid_for(int64_t work) {
     if (blocks > 256 * 8) blocks = 256 * 8;
     if (blocks < 1) blocks = 1;
     return (int)blocks;
+}
+
+// zero-padded box sum along a strided axis (inner > 1) of `total` = n_outer * len * inner values
+void box_axis_strided(const float* in, float* out, int64_t total, int len, int64_t inner, int R, hipStream_t st) {
+    if (R == 5 && inner > 1) {
+        const int64_t n_outer = total / ((int64_t)len * inner);
+        const int64_t threads = n_outer * ((len + 7) / 8) * inner;
+        hipLaunchKernelGGL((box_axis_run_kernel<8, 5>), dim3(grid_for(threads)), dim3(256), 0, st, in, out, n_outer, len, inner);
+    } else {
+        hipLaunchKernelGGL(box_axis_kernel, dim3(grid_for(total)), dim3(256), 0, st, in, out, total, len, inner, R);
+    }
 }
 
 
@@ -274,9 +427,12 @@ hipError_t ssim_l1_fwd_launch(const LossArgs& a, hipStream_t st) {
     float* Bw = a.workspace + 5 * nvox;
     float* partial = a.workspace + 10 * nvox;
     const int nblk = loss_blocks(nvox);
-    hipLaunchKernelGGL(ssim_pass_w_kernel, dim3(grid_for(nvox)), dim3(256), 0, st, a.pred, a.target, A, nvox / a.W, a.W, R);
-    hipLaunchKernelGGL(box_axis_kernel, dim3(grid_for(5 * nvox)), dim3(256), 0, st, A, Bw, 5 * nvox, a.H, (int64_t)a.W, R);
-    hipLaunchKernelGGL(ssim_point_kernel, dim3(nblk), dim3(256), 0, st, Bw, a.pred, a.target, a.gmaps, partial, nvox, a.D, HW, R, inv_win);
+    const bool w4 = R == 5 && a.W % 4 == 0 && ((reinterpret_cast<uintptr_t>(a.pred) | reinterpret_cast<uintptr_t>(a.target) | reinterpret_cast<uintptr_t>(A)) & 15) == 0;
+    if (w4) hipLaunchKernelGGL(ssim_pass_w4_kernel, dim3(grid_for(nvox / 4)), dim3(256), 0, st, a.pred, a.target, A, nvox / a.W, a.W);
+    else hipLaunchKernelGGL(ssim_pass_w_kernel, dim3(grid_for(nvox)), dim3(256), 0, st, a.pred, a.target, A, nvox / a.W, a.W, R);
+    box_axis_strided(A, Bw, 5 * nvox, a.H, a.W, R, st);
+    if (R == 5) hipLaunchKernelGGL((ssim_point_kernel<4, 5>), dim3(nblk), dim3(256), 0, st, Bw, a.pred, a.target, a.gmaps, partial, nvox, a.D, HW, R, inv_win);
+    else hipLaunchKernelGGL((ssim_point_kernel<1, 0>), dim3(nblk), dim3(256), 0, st, Bw, a.pred, a.target, a.gmaps, partial, nvox, a.D, HW, R, inv_win);
     hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(256), 0, st, partial, nblk, a.out, 1.0 / (double)nvox, a.l1_w, a.ssim_w);
     return hipGetLastError();
 }
@@ -288,10 +444,14 @@ hipError_t ssim_l1_bwd_launch(const LossArgs& a, hipStream_t st) {
     const float inv_win = 1.f / ((float)a.window * a.window * a.window);
     float* A = a.workspace;
     float* Bw = a.workspace + 3 * nvox;
-    hipLaunchKernelGGL(box_axis_kernel, dim3(grid_for(3 * nvox)), dim3(256), 0, st, a.gmaps, A, 3 * nvox, a.W, (int64_t)1, R);
-    hipLaunchKernelGGL(box_axis_kernel, dim3(grid_for(3 * nvox)), dim3(256), 0, st, A, Bw, 3 * nvox, a.H, (int64_t)a.W, R);
-    hipLaunchKernelGGL(ssim_grad_kernel, dim3(grid_for(nvox)), dim3(256), 0, st, Bw, a.pred, a.target, a.gscale, a.dpred, nvox, a.D, HW, R, inv_win,
-                       a.l1_w, a.ssim_w);
+    const bool w4 = R == 5 && a.W % 4 == 0 && ((reinterpret_cast<uintptr_t>(a.gmaps) | reinterpret_cast<uintptr_t>(A)) & 15) == 0;
+    if (w4) hipLaunchKernelGGL(box_w4_kernel, dim3(grid_for(3 * nvox / 4)), dim3(256), 0, st, a.gmaps, A, 3 * nvox / a.W, a.W);
+    else hipLaunchKernelGGL(box_axis_kernel, dim3(grid_for(3 * nvox)), dim3(256), 0, st, a.gmaps, A, 3 * nvox, a.W, (int64_t)1, R);
+    box_axis_strided(A, Bw, 3 * nvox, a.H, a.W, R, st);
+    if (R == 5) hipLaunchKernelGGL((ssim_grad_kernel<4, 5>), dim3(grid_for(nvox / 4)), dim3(256), 0, st, Bw, a.pred, a.target, a.gscale, a.dpred, nvox, a.D, HW, R, inv_win,
+                                   a.l1_w, a.ssim_w);
+    else hipLaunchKernelGGL((ssim_grad_kernel<1, 0>), dim3(grid_for(nvox)), dim3(256), 0, st, Bw, a.pred, a.target, a.gscale, a.dpred, nvox, a.D, HW, R, inv_win,
+                            a.l1_w, a.ssim_w);
     return hipGetLastError();
 }
 
