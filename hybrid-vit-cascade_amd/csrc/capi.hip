@@ -386,6 +386,81 @@ int hvc_conv_gemm(int mode, const void* src, const void* other, void* out, int B
     return hip_result(hvc::gemm_launch(g, (hipStream_t)stream), "conv_gemm");
 }
 
+// taps of one axis that reach input positions of parity class p (position = stride * i' + p), as a stride-1 window over dy:
+// n taps, source coordinate i' + e0 + t for t = 0..n-1, tap t is kernel index k0 - t * stride
+static void class_axis(int K, int stride, int P, int p, int& n, int& e0, int& k0) {
+    const int kmin = (p + P) % stride;                    // smallest kernel index with (p + P - k) % stride == 0
+    n = kmin < K ? (K - 1 - kmin) / stride + 1 : 0;
+    k0 = kmin + (n - 1) * stride;                         // largest such index <-> smallest source offset
+    e0 = n ? (p + P - k0) / stride : 0;                   // may be negative (reads in front of dy: zero) or positive
+}
+
+int hvc_conv_dx_class_columns(int KD, int KH, int KW, int stride, int PD, int PH, int PW, int cd, int ch, int cw, int* first_tap, int* ntaps) {
+    if (KD < 1 || KH < 1 || KW < 1 || stride < 1 || cd < 0 || ch < 0 || cw < 0 || cd >= stride || ch >= stride || cw >= stride)
+        return fail(HVC_E_BADARG, "conv_dx_class_columns: bad geometry");
+    int off = 0;
+    for (int d = 0; d < stride; ++d)
+        for (int h = 0; h < stride; ++h)
+            for (int w = 0; w < stride; ++w) {
+                int nd, nh, nw, e, k;
+                class_axis(KD, stride, PD, d, nd, e, k);
+                class_axis(KH, stride, PH, h, nh, e, k);
+                class_axis(KW, stride, PW, w, nw, e, k);
+                if (d == cd && h == ch && w == cw) {
+                    if (first_tap) *first_tap = off;
+                    if (ntaps) *ntaps = nd * nh * nw;
+                    return 0;
+                }
+                off += nd * nh * nw;
+            }
+    return fail(HVC_E_BADARG, "conv_dx_class_columns: class not found");
+}
+
+int hvc_conv_dx_class(const void* dy, const void* wclass, void* dx, int B, int Cout, int OD, int OH, int OW,
+                      int Cin, int SD, int SH, int SW, int KD, int KH, int KW, int stride, int PD, int PH, int PW,
+                      int cd, int ch, int cw, int64_t ld_w, int dtype, void* stream) {
+    if (!dy || !wclass || !dx) return fail(HVC_E_BADARG, "conv_dx_class: null operand");
+    if (B < 1 || Cout < 1 || Cin < 1 || OD < 1 || OH < 1 || OW < 1 || SD < 1 || SH < 1 || SW < 1 || KD < 1 || KH < 1 || KW < 1 || stride < 1)
+        return fail(HVC_E_BADARG, "conv_dx_class: bad extent");
+    if (cd < 0 || ch < 0 || cw < 0 || cd >= stride || ch >= stride || cw >= stride) return fail(HVC_E_BADARG, "conv_dx_class: class out of range");
+    if (!dtype_ok(dtype)) return fail(HVC_E_BADARG, "conv_dx_class: bad dtype");
+    if (Cout % 8 || Cin % 8) return fail(HVC_E_UNSUPPORTED, "conv_dx_class: channel counts must be multiples of 8");
+    if (!aligned16(dy) || !aligned16(wclass) || !aligned16(dx) || ld_w % 8) return fail(HVC_E_BADARG, "conv_dx_class: operands must be 16-byte aligned");
+    int nd, nh, nw, ed, eh, ew, kd0, kh0, kw0;
+    class_axis(KD, stride, PD, cd, nd, ed, kd0);
+    class_axis(KH, stride, PH, ch, nh, eh, kh0);
+    class_axis(KW, stride, PW, cw, nw, ew, kw0);
+    const int cD = cd < SD ? (SD - cd + stride - 1) / stride : 0, cH = ch < SH ? (SH - ch + stride - 1) / stride : 0,
+              cW = cw < SW ? (SW - cw + stride - 1) / stride : 0;                  // input positions of this class per axis
+    if (nd * nh * nw == 0 || cD * cH * cW == 0) return fail(HVC_E_BADARG, "conv_dx_class: empty class (no tap reaches it: those dx values are zero)");
+    const int64_t M = (int64_t)B * cD * cH * cW, K64 = (int64_t)nd * nh * nw * Cout;
+    if (M >= (1ll << 31) || K64 >= (1ll << 31)) return fail(HVC_E_UNSUPPORTED, "conv_dx_class: more than 2^31 rows / columns");
+    hvc::GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    hvc::ConvGather& cg = g.cg;
+    // a stride-1 window of (nd, nh, nw) taps over dy: row (b, i'd, i'h, i'w) reads dy at i' + e0 + t, i.e. "padding" -e0
+    cg.src = dy; cg.C = Cout; cg.SD = OD; cg.SH = OH; cg.SW = OW; cg.KD = nd; cg.KH = nh; cg.KW = nw; cg.stride = 1;
+    cg.PD = -ed; cg.PH = -eh; cg.PW = -ew; cg.flip = 0; cg.M = M; cg.K = (int)K64;
+    const int64_t src_bytes = (int64_t)B * OD * OH * OW * Cout * (dtype == HVC_BF16 ? 2 : 4);
+    static const bool force64 = [] { const char* e = getenv("HVC_CONV_FORCE_ADDR64"); return e && e[0] == '1'; }();
+    cg.bytes = (src_bytes < (1ll << 32) && !force64) ? (uint32_t)src_bytes : 0u;
+    cg.dC = hvc::make_fastdiv((uint32_t)Cout); cg.dKW = hvc::make_fastdiv((uint32_t)nw); cg.dKH = hvc::make_fastdiv((uint32_t)nh);
+    cg.dOW = hvc::make_fastdiv((uint32_t)cW); cg.dOH = hvc::make_fastdiv((uint32_t)cH); cg.dOD = hvc::make_fastdiv((uint32_t)cD);
+    g.gather = cg.bytes ? 1 : 3;
+    g.A = dy; g.lda = K64; g.B = wclass; g.ldb = ld_w;
+    g.M = (int)M; g.N = Cin; g.K = (int)K64; g.rows_per_batch = g.M;
+    g.C = dx; g.ldc = Cin; g.alpha = 1.f; g.act = 0;
+    g.in_bf16 = g.out_bf16 = dtype == HVC_BF16;
+    g.vec_a = 1; g.vec_b = 1; g.vec_epi = 1;
+    // rows of the class result land on the interleaved positions (stride i' + class) of dx [B][SD][SH][SW][Cin]
+    g.omap = 1;
+    g.oW = hvc::make_fastdiv((uint32_t)cW); g.oH = hvc::make_fastdiv((uint32_t)cH); g.oD = hvc::make_fastdiv((uint32_t)cD);
+    g.o_sw = (int64_t)stride * Cin; g.o_sh = (int64_t)stride * SW * Cin; g.o_sd = (int64_t)stride * SH * SW * Cin;
+    g.o_sb = (int64_t)SD * SH * SW * Cin;
+    g.o_base = (((int64_t)cd * SH + ch) * SW + cw) * Cin;
+    return hip_result(hvc::gemm_launch(g, (hipStream_t)stream), "conv_dx_class");
+}
+
 int hvc_col2im(const void* dcol, void* dsrc, int B, int C, int SD, int SH, int SW, int KD, int KH, int KW, int stride,
                int PD, int PH, int PW, int OD, int64_t Kp, int dtype, void* stream) {
     hvc::ConvGeom g;

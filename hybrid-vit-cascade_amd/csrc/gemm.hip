@@ -529,7 +529,13 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) { v[e] = a0[e] * g.alpha + bj[e]; v[4 + e] = a1[e] * g.alpha + bj[4 + e]; }
         }
-        const int64_t co = (int64_t)i * g.ldc + j;
+        int64_t co = (int64_t)i * g.ldc + j;
+        if (g.omap) {
+            const uint32_t q1 = fdiv((uint32_t)i, g.oW), ow = (uint32_t)i - q1 * g.oW.d;
+            const uint32_t q2 = fdiv(q1, g.oH), oh = q1 - q2 * g.oH.d;
+            const uint32_t ob = fdiv(q2, g.oD), od = q2 - ob * g.oD.d;
+            co = g.o_base + (int64_t)ob * g.o_sb + (int64_t)od * g.o_sd + (int64_t)oh * g.o_sh + (int64_t)ow * g.o_sw + j;
+        }
         if (g.act == kActGelu) {
             if (auxp) store_n<TO>(auxp + co, v, nj, vec);
 #pragma unroll

@@ -93,6 +93,11 @@ struct GemmArgs {
     float* workspace;        // optional split-K scratch (fp32), workspace_floats long
     int64_t workspace_floats;
     int splitk;              // filled in by the launcher
+    // optional output row map (one parity class of a strided convolution's input gradient writes its rows into the interleaved
+    // positions of dx): row i = ((b * oD + d) * oH + h) * oW + w  ->  element offset o_base + b o_sb + d o_sd + h o_sh + w o_sw
+    int omap;
+    FastDiv oW, oH, oD;
+    int64_t o_base, o_sb, o_sd, o_sh, o_sw;
     int gather;              // 0: both operands in memory; 1: A = conv patches (k-contiguous view), A / lda unused;
                              // 2: B = conv patches (k-major view: contraction over patch rows), B / ldb unused;
                              // 3 / 4: as 1 / 2 for activation tensors of 4 GiB and more (64-bit addressing)

@@ -42,6 +42,8 @@ SIGNATURES = {
     "hvc_im2col": (_i, [_p, _p] + [_i] * 13 + [_i64, _i, _p]),
     "hvc_col2im": (_i, [_p, _p] + [_i] * 13 + [_i64, _i, _p]),
     "hvc_conv_gemm": (_i, [_i, _p, _p, _p] + [_i] * 14 + [_i64, _i64, _p, _p, _i64, _i, _p, _i64, _i, _i, _p]),
+    "hvc_conv_dx_class_columns": (_i, [_i] * 10 + [_p, _p]),
+    "hvc_conv_dx_class": (_i, [_p, _p, _p] + [_i] * 19 + [_i64, _i, _p]),
     "hvc_trilinear_fwd": (_i, [_p, _p] + [_i] * 8 + [_p]),
     "hvc_trilinear_bwd_workspace": (_i64, [_i] * 7),
     "hvc_trilinear_bwd": (_i, [_p, _p, _p] + [_i] * 8 + [_p]),

@@ -91,7 +91,15 @@ def _conv_w2dT_fill(dst, w):
     dst.view(cin, taps, cout).copy_(w.detach().reshape(cout, cin, taps).permute(1, 2, 0))
 
 
-_CONV_FILL = {"_hvc_w2d": _conv_w2d_fill, "_hvc_w2dT": _conv_w2dT_fill}
+def _conv_w2dC_fill(dst, w):
+    """dst (Cin, taps*Cout) <- w (Cout, Cin, *k) with the taps in the class-major order of the strided input gradient
+    (ops.conv_dx_class_taps); the permutation was stored on the parameter when the copy was first built."""
+    cout, cin = w.shape[0], w.shape[1]
+    taps = w[0, 0].numel()
+    dst.view(cin, taps, cout).copy_(w.detach().reshape(cout, cin, taps).permute(1, 2, 0).index_select(1, w._hvc_w2dC_perm))
+
+
+_CONV_FILL = {"_hvc_w2d": _conv_w2d_fill, "_hvc_w2dT": _conv_w2dT_fill, "_hvc_w2dC": _conv_w2dC_fill}
 
 
 def _after_optimizer_step(optimizer, args, kwargs):
@@ -471,6 +479,31 @@ def conv_weight_2d_t(weight: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     return wt
 
 
+def conv_weight_classes(weight: torch.Tensor, dtype: torch.dtype, geom) -> torch.Tensor:
+    """(Cout, Cin, *k) parameter -> (Cin, taps*Cout) with class-major taps: operand of ops.conv_dx_classes; cached like conv_weight_2d."""
+    sig = (geom.kernel, geom.stride, geom.pad, geom.src[0] > 1 or geom.kernel[0] > 1)
+    key = _cache_key(weight, dtype, sig)
+    hit = getattr(weight, "_hvc_w2dC", None)
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    order = [t for _, taps in ops.conv_dx_class_taps(geom) for t in taps]
+    if sorted(order) != list(range(geom.taps)):
+        raise RuntimeError("conv_weight_classes: every tap must reach exactly one parity class")
+    wc = torch.empty((weight.shape[1], geom.taps * weight.shape[0]), dtype=dtype, device=weight.device)
+    try:
+        weight._hvc_w2dC_perm = torch.tensor(order, dtype=torch.long, device=weight.device)
+        with torch.no_grad():
+            _conv_w2dC_fill(wc, weight)
+        weight._hvc_w2dC = (key, wc)
+        _register(weight, "_hvc_w2dC")
+    except AttributeError:
+        perm = torch.tensor(order, dtype=torch.long, device=weight.device)
+        with torch.no_grad():
+            wc.view(weight.shape[1], geom.taps, weight.shape[0]).copy_(
+                weight.detach().reshape(weight.shape[0], weight.shape[1], geom.taps).permute(1, 2, 0).index_select(1, perm))
+    return wc
+
+
 CONV_IMPLICIT = True          # C % 8 == 0 convolutions gather their patches inside the GEMM (no im2col / col2im round trip)
 CONV_SLAB_BYTES = 2 << 30     # patch matrices larger than this are built (and rebuilt in backward) slab by slab along D
 
@@ -584,6 +617,9 @@ class ConvFn(torch.autograd.Function):
                     assert gd.out == geom.src
                     dx = ops.conv_gemm(dyc.view(geom.B, *geom.out, cout), conv_weight_2d_t(weight, cdt), gd, flip=True)
                     dx = dx.view(geom.B, *geom.src, geom.C)
+                elif cout % 8 == 0:
+                    # strided layer: one implicit GEMM over dy per parity class of the input position, written in place
+                    dx = ops.conv_dx_classes(dyc.view(geom.B, *geom.out, cout), conv_weight_classes(weight, cdt, geom), geom)
                 else:
                     dx = _conv_dx_slabs(dyc.view(geom.B, *geom.out, cout), w2d, geom, cdt)
         elif not slabbed:

@@ -430,6 +430,49 @@ def conv_gemm_dw(x, dy2d, geom):
     return _conv_gemm_call(1, x, dy2d, out, geom, False, N, None, None, 0, ws, max(ws_n, 0), 2.0 * geom.M * N * K)
 
 
+def conv_dx_class_taps(geom):
+    """Class-major tap order of the strided input gradient (hvc_conv_dx_class): a list, over the stride^3 parity classes in
+    (cd, ch, cw) lexicographic order, of (class, [kernel tap indices (kd*KH + kh)*KW + kw in the class's column order])."""
+    s = geom.stride
+
+    def axis(K, P, p):
+        kmin = (p + P) % s
+        n = (K - 1 - kmin) // s + 1 if kmin < K else 0
+        return [kmin + (n - 1 - t) * s for t in range(n)]           # t = 0 <-> largest kernel index (smallest source offset)
+    out = []
+    for cd in range(s if geom.src[0] > 1 or geom.kernel[0] > 1 else 1):
+        for ch in range(s):
+            for cw in range(s):
+                kd, kh, kw = axis(geom.kernel[0], geom.pad[0], cd), axis(geom.kernel[1], geom.pad[1], ch), axis(geom.kernel[2], geom.pad[2], cw)
+                out.append(((cd, ch, cw), [(a * geom.kernel[1] + b) * geom.kernel[2] + c for a in kd for b in kh for c in kw]))
+    return out
+
+
+def conv_dx_classes(dy5, wclass, geom):
+    """Input gradient of a strided convolution as stride^3 implicit GEMMs over dy (one per parity class of the input position),
+    each written to its interleaved positions of dx.  dy5: (B, OD, OH, OW, Cout) contiguous; wclass: (Cin, taps*Cout) in the
+    class-major tap order of conv_dx_class_taps.  Returns dx (B, D, H, W, Cin)."""
+    _dev(dy5, wclass)
+    cout = dy5.shape[-1]
+    if not dy5.is_contiguous() or dy5.shape != (geom.B, *geom.out, cout) or wclass.dtype != dy5.dtype or not wclass.is_contiguous():
+        raise ValueError("conv_dx_classes: contiguous (B,OD,OH,OW,Cout) gradient and a contiguous class-major weight matrix expected")
+    lib = _lib.load()
+    classes = conv_dx_class_taps(geom)
+    empty = any(len(t) == 0 for _, t in classes)
+    dx = (torch.zeros if empty else torch.empty)((geom.B, *geom.src, geom.C), dtype=dy5.dtype, device=dy5.device)
+    col = 0
+    for (cd, ch, cw), taps in classes:
+        n = len(taps)
+        if n and cd < geom.src[0] and ch < geom.src[1] and cw < geom.src[2]:
+            wc = wclass[:, col * cout:(col + n) * cout]
+            with _Timed("gemm_kernel", 2.0 * geom.B * geom.C * n * cout * (geom.src[0] // geom.stride + 1) * (geom.src[1] // geom.stride + 1) * (geom.src[2] // geom.stride + 1)):
+                check(lib.hvc_conv_dx_class(dy5.data_ptr(), wc.data_ptr(), dx.data_ptr(), geom.B, cout, *geom.out, geom.C, *geom.src,
+                                            *geom.kernel, geom.stride, *geom.pad, cd, ch, cw, _ld(wclass), _code(dy5.dtype), _stream()),
+                      "hvc_conv_dx_class")
+        col += n
+    return dx
+
+
 def trilinear_fwd(x, size, align_corners=True):
     """x: (B, d, h, w) fp32 contiguous -> (B, D, H, W)."""
     _dev(x)

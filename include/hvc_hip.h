@@ -226,6 +226,22 @@ int hvc_conv_gemm(int mode, const void* src, const void* other, void* out, int B
                   int64_t ld_out, const float* bias, const float* residual, int64_t ldr, int residual_rows,
                   float* workspace, int64_t workspace_floats, int in_dtype, int out_dtype, void* stream);
 
+/* Input gradient of a STRIDED convolution (stride s > 1) without the dcol matrix and col2im: the input positions split into
+ * s^3 parity classes (position = s * i' + class per axis); within a class every position is reached by the same taps, so
+ * its gradient is a stride-1 implicit GEMM over dy with a (1..ceil(K/s))^3 window, written straight to the class's interleaved
+ * positions of dx.  One call per class; a class no tap reaches (K < s) is rejected - those dx values are zero.
+ *   wclass: the class's columns of W^T[Cin][taps * Cout] re-ordered class-major: classes in (cd, ch, cw) lexicographic order,
+ *           inside a class taps (td, th, tw) lexicographic with t <-> kernel index k0 - t * s per axis (k0 the largest index of
+ *           the class: ascending source offset); hvc_conv_dx_class_columns gives a class's first tap and tap count.
+ *           ld_w = row pitch of that matrix (KD*KH*KW*Cout when all classes share one allocation).
+ * Replaces the backward of the stride-2 nn.Conv3d / nn.Conv2d layers of models/hybrid_vit_backbone.py:195-210 and
+ * direct_regression/progressive_cascade/model_progressive.py:46-49.  Cin % 8 == Cout % 8 == 0. */
+int hvc_conv_dx_class_columns(int KD, int KH, int KW, int stride, int PD, int PH, int PW, int cd, int ch, int cw,
+                              int* first_tap, int* ntaps);
+int hvc_conv_dx_class(const void* dy, const void* wclass, void* dx, int B, int Cout, int OD, int OH, int OW,
+                      int Cin, int SD, int SH, int SW, int KD, int KH, int KW, int stride, int PD, int PH, int PW,
+                      int cd, int ch, int cw, int64_t ld_w, int dtype, void* stream);
+
 /* Trilinear resize of single-channel fp32 volumes [B][d][h][w] -> [B][D][H][W] and its adjoint:
  * align_corners=1 for F.interpolate at models/hybrid_vit_backbone.py:272; align_corners=0 for the cascade's
  * nn.Upsample / F.interpolate (direct_regression/progressive_cascade/model_progressive.py:170,211,239,294). */

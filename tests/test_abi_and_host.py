@@ -50,6 +50,30 @@ def test_bad_arguments_are_rejected_before_any_launch():
     assert rc == -2 and b"axis" in h.hvc_last_error()
 
 
+def test_strided_conv_dx_parity_classes_cover_every_tap_once():
+    """The class-major tap order of the strided input gradient (hvc_conv_dx_class): the host-side C enumeration and the Python
+    one that lays out the weights agree, and every kernel tap belongs to exactly one parity class (k3 s2 p1, k7 s2 p3, k5 s3,
+    k1 s2 with its empty classes, 2-D layers as depth-1 volumes)."""
+    import ctypes
+    from hvc import _lib, ops
+    if not os.path.exists(_lib.LIB_PATH):
+        pytest.skip("libhvc_hip.so not built")
+    h = _lib.load()
+    for src, kernel, stride, pad in (((8, 8, 8), (3, 3, 3), 2, (1, 1, 1)), ((1, 16, 16), (1, 7, 7), 2, (0, 3, 3)), ((9, 9, 9), (5, 5, 5), 3, (2, 2, 2)),
+                                     ((6, 6, 6), (1, 1, 1), 2, (0, 0, 0)), ((1, 12, 12), (1, 3, 3), 2, (0, 1, 1)), ((7, 5, 9), (4, 4, 4), 2, (1, 1, 1))):
+        geom = ops.ConvGeometry(1, 8, src, kernel, stride, pad)
+        classes = ops.conv_dx_class_taps(geom)
+        flat = [t for _, taps in classes for t in taps]
+        assert sorted(flat) == list(range(geom.taps)), (kernel, stride, pad)
+        col = 0
+        for (cd, ch, cw), taps in classes:
+            first, n = ctypes.c_int(-1), ctypes.c_int(-1)
+            assert h.hvc_conv_dx_class_columns(*kernel, stride, *pad, cd, ch, cw, ctypes.byref(first), ctypes.byref(n)) == 0
+            assert (first.value, n.value) == (col, len(taps)), (kernel, stride, (cd, ch, cw))
+            col += len(taps)
+    assert h.hvc_conv_dx_class_columns(3, 3, 3, 2, 1, 1, 1, 2, 0, 0, None, None) != 0 and b"bad geometry" in h.hvc_last_error()
+
+
 def test_cpu_tensors_raise_instead_of_falling_back():
     from hvc import ops
     from models.hybrid_vit_backbone import HybridViT3D

@@ -1201,6 +1201,10 @@ def test_conv_layers_random_geometry(seed, conv_path):
     (True, 1, 16, 8, 1, 1, 0, (9, 10, 11)),        # 1x1x1
     (True, 1, 16, 24, 3, 1, 1, (12, 11, 10)),      # 24 output channels: ragged narrow tiles (256 x 32 forward / dx, 32 x 128 dW)
     (True, 1, 40, 56, 3, 1, 1, (9, 12, 13)),       # 256 x 64 and 64 x 128 tiles with ragged channel counts
+    (True, 1, 8, 16, 5, 3, 2, (11, 10, 12)),       # strided input gradient as parity classes: k5 s3 (27 classes of 1..2 taps per axis)
+    (True, 1, 16, 8, 1, 2, 0, (6, 7, 8)),          # k1 s2: odd positions are reached by no tap (dx = 0 there)
+    (True, 1, 8, 8, 4, 2, 1, (9, 8, 7)),           # even kernel, odd extents
+    (False, 2, 8, 16, 3, 2, 1, (14, 9)),           # 2-D strided layer (cascade X-ray encoder, model_progressive.py:46-49)
 ])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_conv_implicit_gemm_vs_fp64_and_im2col(cfg, dtype):
