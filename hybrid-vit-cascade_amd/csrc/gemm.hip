@@ -670,6 +670,12 @@ hipError_t launch_layout(const GemmArgs& g, hipStream_t st) {
     if (g.gather == 4) return (!g.a_kmajor || !g.b_kmajor) ? hipErrorInvalidValue : launch<TI, TO, true, true, 4>(g, st);
     // Shapes that give the 512 workgroup slots of the chip fewer than ~3/4 of a round of 128 x 128 tiles (the 64^3 model's
     // token matrices: 16384 x 256 = 256 tiles) run on 64 x 128 tiles: twice the workgroups on the same latency chain.
+    // Tall-skinny products (the single-channel convolution layers' patch GEMMs: 16.7 M rows x 32..64 columns at 256^3): 256-row
+    // tiles without the padded columns - half the workgroups, each writing only what exists.
+    if (!g.a_kmajor && g.N <= 64 && g.M >= 4096 && gemm_workspace_floats(g.M, g.N, g.K) == 0) {
+        if (g.N <= 32) return g.b_kmajor ? launch<TI, TO, false, true, 0, TileN32>(g, st) : launch<TI, TO, false, false, 0, TileN32>(g, st);
+        return g.b_kmajor ? launch<TI, TO, false, true, 0, TileN64>(g, st) : launch<TI, TO, false, false, 0, TileN64>(g, st);
+    }
     if (use_half_tile(g)) {
         if (g.a_kmajor) return g.b_kmajor ? launch<TI, TO, true, true, 0, TileM64>(g, st) : launch<TI, TO, true, false, 0, TileM64>(g, st);
         return g.b_kmajor ? launch<TI, TO, false, true, 0, TileM64>(g, st) : launch<TI, TO, false, false, 0, TileM64>(g, st);

@@ -464,7 +464,7 @@ def test_attention_dropout_mask_is_bernoulli_like(p, N):
             assert abs(corr(g[..., a], g[..., b])) < 5 / (n / 4) ** 0.5, ("in-group", a, b)
 
 
-@pytest.mark.parametrize("M,N,K", [(1, 1, 8), (5, 7, 24), (130, 257, 72), (256, 128, 64)])
+@pytest.mark.parametrize("M,N,K", [(1, 1, 8), (5, 7, 24), (130, 257, 72), (256, 128, 64), (4100, 24, 40), (8192, 64, 32), (5000, 33, 100)])
 @pytest.mark.parametrize("akm,bkm", [(False, False), (False, True), (True, True), (True, False)])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_gemm_layouts_and_ragged_shapes(M, N, K, akm, bkm, dtype):
