@@ -156,10 +156,27 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* x, float* partial,
             }
         fold_rows(acc, rl, c8, rlanes, N, red, out, active);
     } else {
-        for (int c = threadIdx.x; c < N; c += 256) {
+        // ragged column counts (the 1-channel output of model_progressive.py:123 gives N = 1): 256 / N rows in flight per
+        // sweep instead of one thread walking a whole column, folded through LDS in a fixed order
+        if (N <= 256) {
+            const int rlanes = 256 / N;
+            const int c = threadIdx.x % N, rl = threadIdx.x / N;
             float s = 0.f;
-            for (int r = r0; r < r1; ++r) s += to_f<T>(x[(int64_t)r * N + c]);
-            out[c] = s;
+            if (rl < rlanes)
+                for (int r = r0 + rl; r < r1; r += rlanes) s += to_f<T>(x[(int64_t)r * N + c]);
+            if (rl < rlanes) red[rl * N + c] = s;
+            __syncthreads();
+            if (threadIdx.x < N) {
+                float tot = 0.f;
+                for (int k = 0; k < rlanes; ++k) tot += red[k * N + threadIdx.x];
+                out[threadIdx.x] = tot;
+            }
+        } else {
+            for (int c = threadIdx.x; c < N; c += 256) {
+                float s = 0.f;
+                for (int r = r0; r < r1; ++r) s += to_f<T>(x[(int64_t)r * N + c]);
+                out[c] = s;
+            }
         }
     }
 }
@@ -208,13 +225,13 @@ hipError_t branch_bwd_launch(const BranchArgs& a, hipStream_t st) {
 
 hipError_t colsum_launch(const void* x, float* partial, float* out, int M, int N, int nblk, int is_bf16, hipStream_t st) {
     const bool vec = (N % 8 == 0) && N <= 2048 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
-    const size_t lds = vec ? (size_t)max(1, 256 / (N / 8)) * N * sizeof(float) : 0;
+    const size_t lds = vec ? (size_t)max(1, 256 / (N / 8)) * N * sizeof(float) : (N <= 256 ? (size_t)(256 / N) * N * sizeof(float) : 0);
     if (is_bf16) {
         if (vec) hipLaunchKernelGGL((colsum_kernel<bf16, true>), dim3(nblk), dim3(256), lds, st, reinterpret_cast<const bf16*>(x), partial, M, N, nblk);
-        else hipLaunchKernelGGL((colsum_kernel<bf16, false>), dim3(nblk), dim3(256), 0, st, reinterpret_cast<const bf16*>(x), partial, M, N, nblk);
+        else hipLaunchKernelGGL((colsum_kernel<bf16, false>), dim3(nblk), dim3(256), lds, st, reinterpret_cast<const bf16*>(x), partial, M, N, nblk);
     } else {
         if (vec) hipLaunchKernelGGL((colsum_kernel<float, true>), dim3(nblk), dim3(256), lds, st, reinterpret_cast<const float*>(x), partial, M, N, nblk);
-        else hipLaunchKernelGGL((colsum_kernel<float, false>), dim3(nblk), dim3(256), 0, st, reinterpret_cast<const float*>(x), partial, M, N, nblk);
+        else hipLaunchKernelGGL((colsum_kernel<float, false>), dim3(nblk), dim3(256), lds, st, reinterpret_cast<const float*>(x), partial, M, N, nblk);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;

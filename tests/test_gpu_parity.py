@@ -500,6 +500,21 @@ def test_gemm_splitk_weight_gradient_shapes(M, N, K, dtype):
     assert ((C1.cpu().double() - ref).abs().max() / (ref.abs().max() + 1e-12)).item() < tol
 
 
+@pytest.mark.parametrize("M,N", [(100000, 1), (5000, 3), (777, 33), (4096, 200), (64, 300), (70000, 256), (33333, 32), (1, 1)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_colsum_bias_gradient_shapes(M, N, dtype):
+    """Column sums (bias gradients: hvc_colsum) incl. the ragged column counts of the cascade's 1-channel output layer
+    (model_progressive.py:123: N = 1, a column of 16.7 M values at 256^3) and of odd channel counts; twice: bit-equal."""
+    from hvc import ops
+    g = torch.Generator().manual_seed(M + N)
+    x = torch.randn(M, N, generator=g).to(dtype).to(dev())
+    a, b = ops.colsum(x), ops.colsum(x)
+    assert torch.equal(a, b)
+    ref = x.double().sum(dim=0).cpu()
+    scale = x.double().abs().sum(dim=0).cpu() + 1e-9
+    assert ((a.cpu().double() - ref).abs() / scale).max().item() < 1e-5
+
+
 @pytest.mark.parametrize("M,N,K", [(2, 1536, 1024), (1, 7, 260), (8, 130, 512), (4, 512, 256)])
 def test_gemm_few_rows_fp32_conditioning_linears(M, N, K):
     """M <= 8 fp32 rows (AdaLNModulation.linear, vit_components.py:131-147; time / context MLPs of diagnostic_losses.py:99-103,
