@@ -77,6 +77,14 @@ def cascade_step(model, criterion, xrays, ct_volume_orig, max_stage):
     return pred, target, criterion(pred, target, stage=3, input_xrays=xrays)
 
 
+def _on_device(dataloader, rank):
+    """Batches one ahead on a side stream (utils/prefetch.py) when the loader yields host tensors; anything else passes through."""
+    if torch.cuda.is_available():
+        from utils.prefetch import DevicePrefetcher
+        return DevicePrefetcher(dataloader, torch.device("cuda", rank % max(torch.cuda.device_count(), 1)))
+    return dataloader
+
+
 def train_step(model, criterion, optimizer, scaler, xrays, ct_volume_orig, max_stage, gradient_clip, autocast_device="cuda"):
     optimizer.zero_grad(set_to_none=True)
     with torch.autocast(autocast_device, dtype=torch.bfloat16):
@@ -101,7 +109,7 @@ def train_epoch(model, dataloader, criterion, optimizer, scaler, rank, epoch, st
     epoch_losses = {"total": 0.0}
     num_batches = 0
     start = time.time()
-    for batch_idx, batch in enumerate(dataloader):
+    for batch_idx, batch in enumerate(_on_device(dataloader, rank)):
         xrays = batch["drr_stacked"].cuda(rank, non_blocking=True)
         ct = batch["ct_volume"].cuda(rank, non_blocking=True)
         loss_dict = train_step(model, criterion, optimizer, scaler, xrays, ct, max_stage, config["training"]["gradient_clip"])

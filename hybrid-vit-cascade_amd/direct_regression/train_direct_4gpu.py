@@ -61,6 +61,14 @@ def wrap_ddp(model, device_ids=None, find_unused_parameters=False):
                find_unused_parameters=find_unused_parameters)
 
 
+def _on_device(dataloader, rank):
+    """Batches one ahead on a side stream (utils/prefetch.py) when the loader yields host tensors; anything else passes through."""
+    if torch.cuda.is_available():
+        from utils.prefetch import DevicePrefetcher
+        return DevicePrefetcher(dataloader, torch.device("cuda", rank % max(torch.cuda.device_count(), 1)))
+    return dataloader
+
+
 def train_step(model, criterion, optimizer, scaler, xrays, ct_volume, gradient_clip, autocast_device="cuda",
                autocast_dtype=torch.bfloat16):
     """One optimisation step (reference train_epoch body, :62-75).  Returns the loss dict.
@@ -89,7 +97,7 @@ def train_epoch(model, dataloader, criterion, optimizer, scaler, rank, epoch, co
     n = 0
     start = time.time()
     world = dist.get_world_size() if dist.is_initialized() else 1
-    for batch_idx, batch in enumerate(dataloader):
+    for batch_idx, batch in enumerate(_on_device(dataloader, rank)):
         xrays = batch["drr_stacked"].cuda(rank, non_blocking=True)
         ct_volume = batch["ct_volume"].cuda(rank, non_blocking=True)
         loss_dict = train_step(model, criterion, optimizer, scaler, xrays, ct_volume, config["training"]["gradient_clip"])

@@ -1606,6 +1606,28 @@ def _stage3_256_step(T, cfg, tmp_path, synthetic, fp8):
 _STAGE3_LOSS = {}
 
 
+def test_device_prefetcher_yields_the_loader_batches_on_the_device():
+    """utils.prefetch.DevicePrefetcher (the trainers' batch loop): same batches, same order, tensors on the GPU, extra keys passed
+    through, and a train_epoch through it matches the plain loop's losses bit for bit."""
+    from utils.prefetch import DevicePrefetcher
+    from torch.utils.data import DataLoader
+    from hvc.synthetic import SyntheticPatientDataset
+    ds = SyntheticPatientDataset(n=5, volume_size=(16, 16, 16), xray_size=64)
+    loader = DataLoader(ds, batch_size=2, shuffle=False, pin_memory=True)
+    plain = list(loader)
+    got = list(DevicePrefetcher(loader, dev()))
+    assert len(got) == len(plain) == 3 and len(DevicePrefetcher(loader, dev())) == 3
+    for a, b in zip(got, plain):
+        assert set(a) == set(b)
+        for k in ("drr_stacked", "ct_volume"):
+            assert a[k].is_cuda and torch.equal(a[k].cpu(), b[k])
+        for k in set(b) - {"drr_stacked", "ct_volume"}:
+            assert (torch.equal(a[k], b[k]) if torch.is_tensor(b[k]) else a[k] == b[k])
+    assert list(DevicePrefetcher([], dev())) == []
+    with pytest.raises(RuntimeError, match="HIP device only"):
+        DevicePrefetcher(loader, "cpu")
+
+
 def test_direct_trainer_checkpoint_resume_on_the_hip_path(tmp_path):
     """save_checkpoint / load_checkpoint of the direct trainer around real HIP steps (reference train_direct_4gpu.py:177-189,
     :273-298): a model + AdamW restored from the checkpoint continue BIT FOR BIT like the run that wrote it - dropout on, so
