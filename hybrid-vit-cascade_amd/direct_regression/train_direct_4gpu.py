@@ -75,19 +75,25 @@ def train_step(model, criterion, optimizer, scaler, xrays, ct_volume, gradient_c
     autocast_dtype=None runs the step in fp32 (split-bf16 MFMA products), the mode the parity fixture uses."""
     optimizer.zero_grad(set_to_none=True)
     with torch.autocast(autocast_device, dtype=autocast_dtype or torch.bfloat16, enabled=autocast_dtype is not None):
-        predicted = model(xrays)
-        loss_dict = criterion(predicted, ct_volume)
+        with HF.trace_range("forward"):
+            predicted = model(xrays)
+        with HF.trace_range("loss"):
+            loss_dict = criterion(predicted, ct_volume)
         total_loss = loss_dict["total_loss"]
     if scaler is not None:
-        scaler.scale(total_loss).backward()
-        scaler.unscale_(optimizer)
-        torch.nn.utils.clip_grad_norm_(model.parameters(), gradient_clip)
-        scaler.step(optimizer)
-        scaler.update()
+        with HF.trace_range("backward"):
+            scaler.scale(total_loss).backward()
+        with HF.trace_range("optimizer"):
+            scaler.unscale_(optimizer)
+            torch.nn.utils.clip_grad_norm_(model.parameters(), gradient_clip)
+            scaler.step(optimizer)
+            scaler.update()
     else:
-        total_loss.backward()
-        torch.nn.utils.clip_grad_norm_(model.parameters(), gradient_clip)
-        optimizer.step()
+        with HF.trace_range("backward"):
+            total_loss.backward()
+        with HF.trace_range("optimizer"):
+            torch.nn.utils.clip_grad_norm_(model.parameters(), gradient_clip)
+            optimizer.step()
     return loss_dict
 
 

@@ -53,10 +53,29 @@ def compute_dtype(ref: torch.Tensor) -> torch.dtype:
 #   * device + storage address cover `p.data = ...` and module.to(device).
 # The one write nothing here can see is an IN-PLACE write through `.data` outside an optimizer (p.data.mul_(..), hand-written
 # EMA updates): same storage, `.data` has its own version counter -- call invalidate_param_casts() after such a write.
+import os
 import weakref
 
 _CAST_EPOCH = 0
 _CAST_REGISTRY = {}          # id(param) -> (weakref(param), attribute name); entries die with their parameter
+
+
+class trace_range:
+    """roctx range around a phase of the step (forward / loss / backward / optimizer) when HVC_TRACE_RANGES=1, so that a
+    `rocprofv3 --marker-trace` timeline shows the phases above the kernels; a no-op otherwise."""
+    ON = os.environ.get("HVC_TRACE_RANGES") == "1"
+
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        if trace_range.ON:
+            torch.cuda.nvtx.range_push(self.name)      # nvtx maps to roctx on ROCm builds of torch
+
+    def __exit__(self, *exc):
+        if trace_range.ON:
+            torch.cuda.nvtx.range_pop()
+        return False
 
 
 def invalidate_param_casts():
