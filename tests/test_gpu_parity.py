@@ -1650,7 +1650,7 @@ def test_direct_trainer_checkpoint_resume_on_the_hip_path(tmp_path):
         torch.manual_seed(seed)                      # the dropout seeds of a step come from the torch generator
         out = T.train_step(m, crit, o, None, xr, ct, 1.0)
         s.step()
-        return float(out["total_loss"])
+        return float(out["total_loss"].detach())
 
     m, o, s = make()
     for i in range(2):
