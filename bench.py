@@ -243,6 +243,9 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     ops.PROFILE, ops.PROFILE_ONLY = None, None
+    if use_graph:
+        loss = loss.detach().clone()          # the graph's static output
+        graphed.close()                       # the eager passes below take their dropout seeds as passed again
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)

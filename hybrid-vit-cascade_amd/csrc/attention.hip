@@ -1169,6 +1169,13 @@ hipError_t set_lds(K kernel, size_t bytes) {
     return e;
 }
 
+// Experiments only (scripts/attn_ab.py): HVC_ATTN_EXTRA_LDS=<bytes> pads every attention launch's dynamic LDS request, e.g. to
+// force one workgroup per CU and read off how much two co-resident waves per SIMD overlap (profiles/r03_attention_*).
+size_t extra_lds() {
+    static const size_t v = [] { const char* e = getenv("HVC_ATTN_EXTRA_LDS"); return e ? (size_t)atol(e) : (size_t)0; }();
+    return v;
+}
+
 template <typename T, int D, bool DROP, bool VEC>
 hipError_t launch_fwd(const AttnArgs& a, hipStream_t st) {
     if constexpr (sizeof(T) == 2 && VEC) {
@@ -1178,13 +1185,16 @@ hipError_t launch_fwd(const AttnArgs& a, hipStream_t st) {
         const char* env = getenv("HVC_ATTN_FWD_ROWS");          // "64" / "32": pin the kernel (parity tests run both on every shape)
         const int force = env ? atoi(env) : 0;
         if (force == 64 || (force != 32 && nqb2 * a.B * a.H >= 512)) {
-            const size_t lds2 = (size_t)2 * 2 * kKT2 * D * sizeof(bf16);
-            hipLaunchKernelGGL((attn_fwd2_kernel<D, DROP>), dim3(nqb2 * a.B * a.H), dim3(256), lds2, st, a);
+            const size_t lds2 = (size_t)2 * 2 * kKT2 * D * sizeof(bf16) + extra_lds();
+            auto k2 = attn_fwd2_kernel<D, DROP>;
+            hipError_t e2 = set_lds(k2, lds2);
+            if (e2 != hipSuccess) return e2;
+            hipLaunchKernelGGL(k2, dim3(nqb2 * a.B * a.H), dim3(256), lds2, st, a);
             return hipGetLastError();
         }
     }
     const int nqb = (a.Nq + kQB - 1) / kQB;
-    const size_t lds = fwd_lds_bytes<T, D>();
+    const size_t lds = fwd_lds_bytes<T, D>() + extra_lds();
     auto k = attn_fwd_kernel<T, D, DROP, VEC>;
     hipError_t e = set_lds(k, lds);
     if (e != hipSuccess) return e;
@@ -1203,7 +1213,7 @@ hipError_t launch_bwd(const AttnArgs& a, hipStream_t st) {
     }
     if (ph & 2) {
         const int nkb = (a.Nk + kQB - 1) / kQB;
-        const size_t lds = dkv_lds_bytes<T, D>(DROP);
+        const size_t lds = dkv_lds_bytes<T, D>(DROP) + extra_lds();
         auto k = attn_bwd_dkv_kernel<T, D, DROP, VEC>;
         hipError_t e = set_lds(k, lds);
         if (e != hipSuccess) return e;
@@ -1226,7 +1236,7 @@ hipError_t launch_bwd(const AttnArgs& a, hipStream_t st) {
     }
     if (ph & 4) {
         const int nqb = (a.Nq + kQB - 1) / kQB;
-        const size_t lds = fwd_lds_bytes<T, D>();
+        const size_t lds = fwd_lds_bytes<T, D>() + extra_lds();
         auto k = attn_bwd_dq_kernel<T, D, DROP, VEC>;
         hipError_t e = set_lds(k, lds);
         if (e != hipSuccess) return e;

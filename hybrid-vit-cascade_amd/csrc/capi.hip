@@ -5,15 +5,18 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
+
 #include "../../include/hvc_hip.h"
 #include "hvc_kernels.h"
 
 namespace {
 
 thread_local char g_err[256] = "";
-// Device word every dropout seed is offset by (hvc_set_seed_counter); null = seeds are taken as passed.  Per thread, like the
-// HIP current-device state: one process (and one trainer thread) per GPU.
-thread_local const uint32_t* g_seed_ctr = nullptr;
+// Device word every dropout seed is offset by (hvc_set_seed_counter); null = seeds are taken as passed.  PROCESS-wide (one
+// process per GPU): torch runs the backward of an autograd Function on its device worker thread, not on the thread that set the
+// counter, and the forward and backward of one step must fold the same word into their seeds.
+std::atomic<const uint32_t*> g_seed_ctr{nullptr};
 
 __global__ void seed_counter_advance_kernel(uint32_t* ctr, uint32_t step) { *ctr += step; }
 
@@ -45,7 +48,7 @@ int hvc_abi_version(void) { return HVC_ABI_VERSION; }
 const char* hvc_last_error(void) { return g_err; }
 
 int hvc_set_seed_counter(const uint32_t* device_counter) {
-    g_seed_ctr = device_counter;
+    g_seed_ctr.store(device_counter);
     return 0;
 }
 
@@ -89,7 +92,7 @@ static int fill_attn(hvc::AttnArgs& a, const void* q, const void* k, const void*
     a.dk_sb = k_sb; a.dk_sn = k_sn; a.dk_sh = k_sh;
     a.dv_sb = v_sb; a.dv_sn = v_sn; a.dv_sh = v_sh;
     a.scale = scale;
-    a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32); a.seed_ctr = g_seed_ctr;
+    a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32); a.seed_ctr = g_seed_ctr.load();
     a.drop_thresh = drop_threshold(p_drop);
     a.keep_scale = 1.f / (1.f - p_drop);
     a.is_bf16 = dtype == HVC_BF16;
@@ -180,7 +183,7 @@ int hvc_gemm(const void* A, const void* B, void* C, int M, int N, int K,
     g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.a_kmajor = a_kmajor != 0; g.b_kmajor = b_kmajor != 0;
     g.alpha = alpha; g.bias = bias; g.act = act; g.aux = aux; g.zsave = zsave; g.ldz = ldz; g.gate = gate; g.residual = residual; g.ldr = ldr; g.residual_rows = residual_rows > 0 ? residual_rows : 0;
     g.rows_per_batch = rows_per_batch > 0 ? rows_per_batch : M;
-    g.seed_lo = (uint32_t)seed; g.seed_hi = (uint32_t)(seed >> 32); g.seed_ctr = g_seed_ctr;
+    g.seed_lo = (uint32_t)seed; g.seed_hi = (uint32_t)(seed >> 32); g.seed_ctr = g_seed_ctr.load();
     g.drop_thresh = drop_threshold(p_drop);
     g.keep_scale = 1.f / (1.f - p_drop);
     g.in_bf16 = in_dtype == HVC_BF16; g.out_bf16 = out_dtype == HVC_BF16;
@@ -257,7 +260,7 @@ int hvc_branch_bwd(const float* dy, const void* z, const float* gate, void* dz, 
     a.rows = rows; a.N = N; a.rows_per_batch = rows_per_batch; a.blocks_per_batch = hvc::rowops_blocks(rows_per_batch);
     a.out_bf16 = out_dtype == HVC_BF16;
     if (!(p_drop >= 0.f) || !(p_drop < 1.f)) return fail(HVC_E_BADARG, "branch_bwd: bad p_drop");
-    a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32); a.seed_ctr = g_seed_ctr;
+    a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32); a.seed_ctr = g_seed_ctr.load();
     a.drop_thresh = drop_threshold(p_drop); a.keep_scale = 1.f / (1.f - p_drop);
     return hip_result(hvc::branch_bwd_launch(a, (hipStream_t)stream), "branch_bwd");
 }

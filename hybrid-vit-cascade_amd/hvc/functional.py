@@ -26,7 +26,9 @@ def set_fp8_attention(on: bool) -> None:
 
 
 def _fp8(t) -> bool:
-    return ATTN_FP8 and t.dtype == torch.bfloat16
+    """fp8 forward for this operand?  Only bf16 operands with a head dim the fp8 kernel is built for (32 / 64: the cascade's and
+    the direct model's heads); anything else keeps the bf16 kernel."""
+    return ATTN_FP8 and t.dtype == torch.bfloat16 and t.shape[-1] in (32, 64)
 
 
 def compute_dtype(ref: torch.Tensor) -> torch.dtype:
@@ -122,10 +124,13 @@ _CONV_FILL = {"_hvc_w2d": _conv_w2d_fill, "_hvc_w2dT": _conv_w2dT_fill, "_hvc_w2
 
 
 def _after_optimizer_step(optimizer, args, kwargs):
-    """Refresh every live cached copy from its (just updated) parameter: plain casts in ONE multi-tensor copy, conv layouts
-    by one strided cast each; entries whose parameter moved (device / storage) or vanished are dropped and rebuilt lazily."""
+    """Refresh, in place, the cached copies of the parameters THIS optimizer just updated (fused AdamW does not bump their
+    version counters): plain casts in ONE multi-tensor copy, conv layouts by one strided cast each.  Copies of parameters that
+    belong to no group of this optimizer (frozen cascade stages, a second model, an EMA) keep their contents and are only
+    re-keyed to the new epoch; entries whose parameter moved (device / storage) or vanished are dropped and rebuilt lazily."""
     global _CAST_EPOCH
-    _CAST_EPOCH += 1
+    _CAST_EPOCH += 1          # any copy this hook does not know about is stale from here on
+    mine = {id(q) for group in optimizer.param_groups for q in group["params"] if q.requires_grad}
     srcs, dsts, rekey = [], [], []
     for key, (ref, attr) in list(_CAST_REGISTRY.items()):
         p = ref()
@@ -134,6 +139,9 @@ def _after_optimizer_step(optimizer, args, kwargs):
             _CAST_REGISTRY.pop(key, None)
             continue
         old_key, dst = hit
+        if key[0] not in mine:                 # not updated by this optimizer: the copy is still right, only its key moves on
+            rekey.append((p, attr, old_key, dst))
+            continue
         if attr == "_hvc_cast":
             srcs.append(p.detach())
             dsts.append(dst)
@@ -823,8 +831,9 @@ class ViewMeanGapFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dmean, dpooled):
         V, dtype = ctx.cfg
-        if dmean is None:
-            dmean = torch.zeros((dpooled.shape[0], 1, 1), device=dpooled.device)     # never the case on the hot path
-            raise RuntimeError("ViewMeanGapFn: the feature-map gradient is required")
-        df = ops.view_mean_gap_bwd(_f32(dmean), None if dpooled is None else _f32(dpooled), V, dtype)
+        if not ctx.needs_input_grad[0]:          # frozen encoder: no feature-map gradient to form
+            return None, None
+        # both outputs are always used downstream (context tokens and the pooled conditioning), and autograd materialises
+        # the gradient of an unused one as zeros
+        df = ops.view_mean_gap_bwd(_f32(dmean), _f32(dpooled), V, dtype)
         return df, None

@@ -26,6 +26,7 @@ class GraphedStep:
             # recorded inside the graph would run again on every replay and reset that state
             raise ValueError("GraphedStep needs at least one eager warm-up step ahead of the capture")
         self.lib = _lib.load()
+        self._closed = False
         self.static_inputs = [t.clone() for t in example_inputs]
         dev = self.static_inputs[0].device
         self.counter = torch.zeros(1, dtype=torch.int32, device=dev)          # read as uint32 on the device
@@ -42,11 +43,29 @@ class GraphedStep:
         with torch.cuda.graph(self.graph):
             self._advance(torch.cuda.current_stream(dev))
             self.static_outputs = step_fn(*self.static_inputs)
+        # The graph has baked in the addresses of the cached compute-dtype / conv-layout weight copies (hvc.functional): hold
+        # them, and refuse to replay once a parameter's copy has been rebuilt elsewhere (invalidate_param_casts, a
+        # load_state_dict, a dtype switch) - the replay would read and refresh buffers nobody else uses any more.
+        from . import functional as F
+        self._pinned = []
+        for (pid, attr), (ref, _) in list(F._CAST_REGISTRY.items()):
+            prm = ref()
+            hit = getattr(prm, attr, None) if prm is not None else None
+            if hit is not None:
+                self._pinned.append((ref, attr, hit[1]))
 
     def _advance(self, stream):
         _lib.check(self.lib.hvc_seed_counter_advance(self.counter.data_ptr(), 1, stream.cuda_stream), "hvc_seed_counter_advance")
 
     def __call__(self, *inputs):
+        if self._closed:
+            raise RuntimeError("GraphedStep was closed")
+        for ref, attr, dst in self._pinned:
+            prm = ref()
+            hit = getattr(prm, attr, None) if prm is not None else None
+            if hit is None or hit[1] is not dst:
+                raise RuntimeError("a cached weight copy captured by this graph was rebuilt (parameters re-cast or reloaded "
+                                   "since the capture): build a new GraphedStep")
         for dst, src in zip(self.static_inputs, inputs):
             if dst.data_ptr() != src.data_ptr():
                 dst.copy_(src, non_blocking=True)
@@ -54,5 +73,22 @@ class GraphedStep:
         return self.static_outputs
 
     def close(self):
-        """Detach the device counter from the library (seeds are taken as passed again)."""
+        """Detach the device counter from the library (seeds are taken as passed again).  Idempotent; also runs when the object
+        is dropped or leaves a `with` block - the library must not keep reading a freed counter word."""
+        if getattr(self, "_closed", True):      # never opened (the constructor failed early) or closed already
+            return
+        self._closed = True
         _lib.check(self.lib.hvc_set_seed_counter(None), "hvc_set_seed_counter")
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -99,7 +99,10 @@ def attention_fwd(q, k, v, scale, p_drop=0.0, seed=0, fp8=False):
         if q.dtype != torch.bfloat16:
             raise TypeError("fp8 attention takes bfloat16 operands (run it under torch.autocast)")
         lib = _lib.load()
-        ws = torch.empty((lib.hvc_attention_fwd_fp8_workspace(B, H, Nk, D),), dtype=torch.uint8, device=q.device)
+        nbytes = lib.hvc_attention_fwd_fp8_workspace(B, H, Nk, D)
+        if nbytes < 0:
+            raise ValueError(f"fp8 attention supports head dims 32 and 64 (got D = {D})")
+        ws = torch.empty((nbytes,), dtype=torch.uint8, device=q.device)
         with _Timed("attn_fwd_fp8_kernel", 4.0 * B * H * Nq * Nk * D):
             check(lib.hvc_attention_fwd_fp8(
                 q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse.data_ptr(), ws.data_ptr(), B, H, Nq, Nk, D,
@@ -684,13 +687,11 @@ def view_mean_gap_fwd(feats, V):
 
 
 def view_mean_gap_bwd(dmean, dpooled, V, dtype):
+    if dmean is None:
+        raise ValueError("view_mean_gap_bwd: dmean (B, P, E) is required, it gives the geometry")
     _dev(dmean, dpooled)
-    ref = dmean if dmean is not None else dpooled
-    if dmean is not None:
-        B, P, E = dmean.shape
-    else:
-        raise ValueError("view_mean_gap_bwd: dmean gives the geometry")
-    df = torch.empty((B * V, P, E), dtype=dtype, device=ref.device)
+    B, P, E = dmean.shape
+    df = torch.empty((B * V, P, E), dtype=dtype, device=dmean.device)
     check(_lib.load().hvc_view_mean_gap_bwd(_ptr(_f32c(dmean, "dmean")), _ptr(_f32c(dpooled, "dpooled")), df.data_ptr(), B, V, P, E, _code(dtype),
                                             _stream()), "hvc_view_mean_gap_bwd")
     return df

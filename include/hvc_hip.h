@@ -45,7 +45,8 @@ const char* hvc_last_error(void);
  * backward passes) offsets its 64-bit seed argument by the 32-bit word at ptr, read on the device at kernel start; forward and
  * backward of one step see the same value and so regenerate the same masks.  hvc_seed_counter_advance enqueues a one-thread
  * kernel adding `step` to the word - captured as the first node of the step's graph.  NULL restores plain seeds.  The
- * setting is per host thread.  (The reference draws its masks from torch's Philox stream: train_direct_4gpu.py:65-71.) */
+ * setting is process-wide (one process per GPU): autograd runs backward passes on its own worker thread, which must see the
+ * counter the forward saw.  (The reference draws its masks from torch's Philox stream: train_direct_4gpu.py:65-71.) */
 int hvc_set_seed_counter(const uint32_t* device_counter);
 int hvc_seed_counter_advance(uint32_t* device_counter, uint32_t step, void* stream);
 

@@ -464,6 +464,33 @@ def test_attention_dropout_mask_is_bernoulli_like(p, N):
             assert abs(corr(g[..., a], g[..., b])) < 5 / (n / 4) ** 0.5, ("in-group", a, b)
 
 
+def test_seed_counter_is_seen_by_the_autograd_thread():
+    """hvc_set_seed_counter is process-wide: the backward of an autograd Function runs on torch's device worker
+    thread and must fold the SAME device counter into its dropout seed as the forward did on the caller's thread.  The
+    GEMM-epilogue dropout of hvc.functional.linear: recover the forward's mask from its zeros, and require the input gradient
+    to be the one of exactly that mask."""
+    from hvc import _lib, functional as HF
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(64, 96, generator=g).to(dev()).requires_grad_(True)
+    w = torch.randn(128, 96, generator=g).to(dev())
+    counter = torch.full((1,), 5, dtype=torch.int32, device=dev())
+    _lib.check(lib.hvc_set_seed_counter(counter.data_ptr()), "hvc_set_seed_counter")
+    try:
+        y = HF.linear(x, w, None, cdt=torch.float32, out_dtype=torch.float32, p_drop=0.5, seed=31)
+        y.sum().backward()                                                        # backward: autograd worker thread
+        keep = (y.detach() != 0).float()
+        assert 0.4 < keep.mean().item() < 0.6
+        want = (keep / 0.5) @ w
+        assert ((x.grad - want).abs().max() / want.abs().max()).item() < F32_TOL
+        y0 = HF.linear(x.detach(), w, None, cdt=torch.float32, out_dtype=torch.float32, p_drop=0.5, seed=31)
+        _lib.check(lib.hvc_set_seed_counter(None), "hvc_set_seed_counter")
+        y1 = HF.linear(x.detach(), w, None, cdt=torch.float32, out_dtype=torch.float32, p_drop=0.5, seed=31)
+        assert torch.equal(y0, y.detach()) and not torch.equal(y1 != 0, y0 != 0)          # the counter really moved the mask
+    finally:
+        _lib.check(lib.hvc_set_seed_counter(None), "hvc_set_seed_counter")
+
+
 @pytest.mark.parametrize("M,N,K", [(1, 1, 8), (5, 7, 24), (130, 257, 72), (256, 128, 64), (4100, 24, 40), (8192, 64, 32), (5000, 33, 100)])
 @pytest.mark.parametrize("akm,bkm", [(False, False), (False, True), (True, True), (True, False)])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
