@@ -83,18 +83,50 @@ def train_step(model, params, crit, opt, xr, ct):
     return loss
 
 
-def cpu_baseline(seconds_budget=30.0):
-    """Oracle (CPU restatement pinned to the reference) timed on the host cores: BASELINE config #1,
-    one train step = fwd + L1 + 0.5 SSIM + bwd + clip + AdamW, Direct 64^3, batch 1, fp32."""
+def _host_cores():
+    """(threads to use, description): the physical cores this process may run on (one GPU's share of the host on a shared box)."""
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        allowed = list(range(os.cpu_count() or 1))
+    model, phys, cur = "unknown", set(), {}
+    try:
+        for line in open("/proc/cpuinfo"):
+            if ":" not in line:
+                if cur.get("processor") in allowed:
+                    phys.add((cur.get("physical id", 0), cur.get("core id", cur.get("processor"))))
+                cur = {}
+                continue
+            k, v = (x.strip() for x in line.split(":", 1))
+            if k == "model name":
+                model = v
+            if k in ("processor", "physical id", "core id"):
+                cur[k] = int(v)
+    except OSError:
+        pass
+    n = len(phys) if phys else len(allowed)
+    desc = f"{model}: {n} physical cores of {len(allowed)} logical CPUs visible to this process"
+    try:      # a container's CPU share (cgroup v2 quota): more threads than that only get throttled
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            share = max(1, int(int(quota) / int(period)))
+            if share < n:
+                desc += f"; cgroup CPU quota {share} cores"
+                n = share
+    except (OSError, ValueError):
+        pass
+    return max(1, n), desc
+
+
+def cpu_baseline():
+    """Oracle (CPU restatement pinned to the reference) timed on the host cores, protocol of BASELINE.md section 3: BASELINE
+    config #1 (Direct 64^3, 2-view 512^2, batch 1, fp32, train mode), one step = zero_grad -> forward -> L1 + 0.5 SSIM ->
+    backward -> clip_grad_norm_(1.0) -> AdamW(1e-4, wd 0.01); torch.set_num_threads(all physical cores); 2 warm-up + 5 timed
+    steps, median (1 + 3 if a step takes longer than 12 s, so that the default run stays within a few minutes)."""
     from direct_regression.model_direct import DirectCTRegression
     from hvc import synthetic
     from oracle import hvc_oracle as O
-    cores = os.cpu_count() or 1
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        pass
-    cores = min(cores, 16)          # one GPU's share of the host on the 8-GPU box; more threads oversubscribe
+    cores, host = _host_cores()
     torch.set_num_threads(cores)
     torch.manual_seed(0)
     m = DirectCTRegression(volume_size=(64, 64, 64))
@@ -103,9 +135,8 @@ def cpu_baseline(seconds_budget=30.0):
     leaves = [v for v in P.values() if v.requires_grad]
     opt = torch.optim.AdamW(leaves, lr=1e-4, weight_decay=0.01)
     xr, ct = synthetic.batch(0, 1, (64, 64, 64), 512)
-    times = []
-    t_all = time.perf_counter()
-    while True:
+
+    def one_step():
         t0 = time.perf_counter()
         opt.zero_grad(set_to_none=True)
         pred = O.direct_ct_regression(xr, P, training=True, new_stats={}, p_drop=0.1)
@@ -113,33 +144,43 @@ def cpu_baseline(seconds_budget=30.0):
         loss.backward()
         torch.nn.utils.clip_grad_norm_(leaves, 1.0)
         opt.step()
-        times.append(time.perf_counter() - t0)
-        if len(times) >= 6 or time.perf_counter() - t_all > seconds_budget * 0.4:
-            break
-    best = min(times)
-    return {"value": 1.0 / best, "unit": "volumes/s", "cores": cores, "kind": "port",
-            "sample": f"{len(times)} train step(s) of Direct 64^3, batch 1, fp32 (BASELINE config #1: fwd + L1+0.5*SSIM + bwd + "
-                      f"clip + AdamW, train mode with the reference's dropout draws p=0.1) through oracle/hvc_oracle.py on "
-                      f"{cores} threads, best step {best:.2f} s"}
+        return time.perf_counter() - t0
+    first = one_step()
+    warm, timed = (2, 5) if first <= 12.0 else (1, 3)
+    for _ in range(warm - 1):
+        one_step()
+    times = sorted(one_step() for _ in range(timed))
+    med = times[len(times) // 2]
+    return {"value": 1.0 / med, "unit": "volumes/s", "cores": cores, "kind": "port", "host": host,
+            "torch": torch.__version__, "s_per_step_median": med, "s_per_step_all": times,
+            "sample": f"{warm} warm-up + {timed} timed train steps of Direct 64^3, batch 1, fp32 (BASELINE config #1: fwd + L1+0.5*SSIM + "
+                      f"bwd + clip + AdamW, train mode with the reference's dropout draws p=0.1) through oracle/hvc_oracle.py on "
+                      f"{cores} threads, median step {med:.2f} s"}
 
 
 def other_resolutions(main_workload):
-    """north_star quotes volumes/s at 64^3, 128^3 and 256^3: short runs of the other two resolutions (child processes of this
-    one, 10 timed steps each), reported beside the headline line."""
+    """north_star quotes volumes/s at 64^3, 128^3 and 256^3 "as absolute and as fraction of roofline": short runs of the other two
+    resolutions (child processes of this one, 10 timed steps each, HIP events on their attention kernels), each with its own
+    roofline object (dominant kernel, algorithmic flops / measured launch time / dense bf16 MFMA peak) beside the headline line."""
     import subprocess
     out = {}
     for wl in ("direct64", "direct128", "direct256"):
         if wl == main_workload:
             continue
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", wl, "--steps", "10", "--warmup", "3", "--no-cpu-baseline",
-                            "--no-extra", "--no-profile"], capture_output=True, text=True, timeout=900)
+                            "--no-extra"], capture_output=True, text=True, timeout=900)
         line = next((ln for ln in r.stdout.splitlines() if ln.startswith("{")), None)
         if r.returncode or line is None:
             out[wl] = {"error": (r.stderr or r.stdout)[-300:]}
             continue
         d = json.loads(line)
         out[wl] = {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "batch_per_gpu": d["config"]["batch_per_gpu"],
-                   "tokens": d["config"]["tokens"], "launch": d["config"]["launch"], "steps": d["steps"]}
+                   "tokens": d["config"]["tokens"], "launch": d["config"]["launch"], "steps": d["steps"],
+                   "algorithmic_tflops_per_volume_fwd_bwd": d["algorithmic_tflops_per_volume_fwd_bwd"],
+                   "achieved_model_tflops_per_gpu": d["achieved_model_tflops_per_gpu"],
+                   "model_frac_of_mfma_peak": d["achieved_model_tflops_per_gpu"] / MFMA_BF16_PEAK_TFLOPS,
+                   "roofline": d.get("roofline"),
+                   "kernel_ms_per_step": {k: round(v["ms_per_step"], 3) for k, v in d.get("kernel_time_share", {}).items()}}
     return out
 
 
@@ -153,8 +194,8 @@ def _free_port():
 def spawn_ranks(n):
     """Run this script as n ranks under torch.distributed.run (one process per GPU); returns the launcher's exit code."""
     import subprocess
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL needs it on this driver
+    from hvc.dist_env import ensure_rccl_env
+    env = ensure_rccl_env(dict(os.environ))                 # dmabuf IPC for RCCL: one definition for every launcher (hvc/dist_env.py)
     env.setdefault("OMP_NUM_THREADS", "4")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
@@ -173,6 +214,8 @@ def main():
                     help="replay the step as one captured hipGraph (auto: for the launch-bound direct64 workload, single GPU)")
     ap.add_argument("--no-extra", action="store_true", help="skip the short 64^3 / 256^3 runs reported under other_resolutions")
     args = ap.parse_args()
+    from hvc.dist_env import ensure_rccl_env
+    ensure_rccl_env()          # also when an external launcher started this rank; no HIP call has been made yet
 
     if args.gpus > 1 and "RANK" not in os.environ:
         # Plain `python bench.py --gpus N`: start the N ranks ourselves (the reference does the same with mp.spawn,
@@ -246,10 +289,13 @@ def main():
     if use_graph:
         loss = loss.detach().clone()          # the graph's static output
         graphed.close()                       # the eager passes below take their dropout seeds as passed again
+    rank_ms = None
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = t.item()
+        every = [torch.zeros_like(t) for _ in range(world)]
+        torch.distributed.all_gather(every, t)
+        rank_ms = [1e3 * x.item() / args.steps for x in every]
+        elapsed = max(x.item() for x in every)               # the slowest rank's clock is the job's
     roofline_note = f"the {args.steps} timed steps (HIP events on the launch stream)"
     if use_graph and not args.no_profile:
         prof = []
@@ -327,6 +373,11 @@ def main():
         if world > 1:
             out["rccl_ranks"] = torch.distributed.get_world_size()
             out["dist_backend"] = torch.distributed.get_backend()
+            out["rank_ms_per_step"] = {"min": min(rank_ms), "max": max(rank_ms)}
+            out["ipc_env"] = {"HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")}
+            # scaling comparator: the step runs eagerly under DDP (its bucketed all-reduce is not captured), so the N = 1 point of
+            # a scaling curve for this workload is the eager one
+            out["n1_comparator"] = f"python bench.py --workload {args.workload} --graph off"
             try:
                 out["nccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
             except Exception:       # noqa: BLE001 - informational only

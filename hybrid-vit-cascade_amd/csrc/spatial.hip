@@ -186,6 +186,39 @@ __global__ __launch_bounds__(256) void trilinear_fwd_kernel(const float* __restr
     }
 }
 
+// W % 4 == 0: one thread = four consecutive outputs of a row.  The index decode, the two outer axis maps and the four source row
+// bases are shared by the four outputs, which leave as one 16-byte store (the scalar kernel spends ~60 instructions and a 4-byte
+// store per element: instruction-bound at 0.7 TB/s of output on 16 x 256^3).  Same expression per element: bit-identical results.
+__global__ __launch_bounds__(256) void trilinear_fwd4_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                              int B, int d, int h, int w, int D, int H, int W, int ac) {
+    const AxisMap md = axis_map(d, D, ac), mh = axis_map(h, H, ac), mw = axis_map(w, W, ac);
+    const int W4 = W >> 2;
+    const int64_t total = (int64_t)B * D * H * W4;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const Pos o = decode(idx, D, H, W4);      // o.w = group of four along W
+        const float fd = md.src(o.d), fh = mh.src(o.h);
+        const int d0 = min((int)fd, d - 1), h0 = min((int)fh, h - 1);
+        const int d1 = min(d0 + 1, d - 1), h1 = min(h0 + 1, h - 1);
+        const float ld = fd - d0, lh = fh - h0;
+        const float* s = src + (int64_t)o.b * d * h * w;
+        const float* r00 = s + ((int64_t)d0 * h + h0) * w;
+        const float* r01 = s + ((int64_t)d0 * h + h1) * w;
+        const float* r10 = s + ((int64_t)d1 * h + h0) * w;
+        const float* r11 = s + ((int64_t)d1 * h + h1) * w;
+        f32x4 out;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float fw = mw.src(4 * o.w + j);
+            const int w0 = min((int)fw, w - 1);
+            const int w1 = min(w0 + 1, w - 1);
+            const float lw = fw - w0;
+            out[j] = (1 - ld) * ((1 - lh) * ((1 - lw) * r00[w0] + lw * r00[w1]) + lh * ((1 - lw) * r01[w0] + lw * r01[w1])) +
+                     ld * ((1 - lh) * ((1 - lw) * r10[w0] + lw * r10[w1]) + lh * ((1 - lw) * r11[w0] + lw * r11[w1]));
+        }
+        *reinterpret_cast<f32x4*>(dst + (((int64_t)o.b * D + o.d) * H + o.h) * W + 4 * o.w) = out;
+    }
+}
+
 // weight of fine index o onto coarse index i along one axis (mirrors the forward's i0 / i1 / lambda)
 __device__ __forceinline__ float axis_w(int o, int i, const AxisMap& m, int in) {
     const float f = m.src(o);
@@ -295,7 +328,9 @@ hipError_t col2im_launch(const ConvGeom& g, const void* dcol, void* dsrc, int is
 hipError_t trilinear_launch(const float* src, float* dst, int B, int d, int h, int w, int D, int H, int W, bool align_corners, bool bwd,
                             hipStream_t st) {
     const int ac = align_corners ? 1 : 0;
-    if (!bwd) hipLaunchKernelGGL(trilinear_fwd_kernel, dim3(grid_for((int64_t)B * D * H * W)), dim3(256), 0, st, src, dst, B, d, h, w, D, H, W, ac);
+    if (!bwd && (W & 3) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15u) == 0)
+        hipLaunchKernelGGL(trilinear_fwd4_kernel, dim3(grid_for((int64_t)B * D * H * (W >> 2))), dim3(256), 0, st, src, dst, B, d, h, w, D, H, W, ac);
+    else if (!bwd) hipLaunchKernelGGL(trilinear_fwd_kernel, dim3(grid_for((int64_t)B * D * H * W)), dim3(256), 0, st, src, dst, B, d, h, w, D, H, W, ac);
     else hipLaunchKernelGGL(trilinear_bwd_kernel, dim3(grid_for((int64_t)B * d * h * w * 64)), dim3(256), 0, st, src, dst, B, d, h, w, D, H, W, ac);
     return hipGetLastError();
 }

@@ -242,6 +242,8 @@ def main_worker(rank, world_size, config, stages=(1, 2, 3), synthetic=False):
 
 
 def main():
+    from hvc.dist_env import ensure_rccl_env
+    ensure_rccl_env()          # before any HIP call of this process and of the ranks it spawns
     ap = argparse.ArgumentParser(description="Progressive cascade training, data-parallel on MI355X")
     ap.add_argument("--config", type=str, default=str(Path(__file__).parent / "config_progressive.json"))
     ap.add_argument("--stages", type=int, nargs="+", default=[1, 2, 3], choices=[1, 2, 3])

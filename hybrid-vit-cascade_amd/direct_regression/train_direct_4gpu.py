@@ -224,6 +224,8 @@ def train_ddp(rank, world_size, config, resume_from=None, synthetic=False):
 
 
 def main():
+    from hvc.dist_env import ensure_rccl_env
+    ensure_rccl_env()          # before any HIP call of this process and of the ranks it spawns
     ap = argparse.ArgumentParser(description="Direct CT regression, data-parallel on MI355X")
     ap.add_argument("--config", type=str, default=os.path.join(os.path.dirname(os.path.abspath(__file__)), "config_direct.json"))
     ap.add_argument("--resume", type=str, default=None)

@@ -129,6 +129,7 @@ def _after_optimizer_step(optimizer, args, kwargs):
     belong to no group of this optimizer (frozen cascade stages, a second model, an EMA) keep their contents and are only
     re-keyed to the new epoch; entries whose parameter moved (device / storage) or vanished are dropped and rebuilt lazily."""
     global _CAST_EPOCH
+    before = _CAST_EPOCH
     _CAST_EPOCH += 1          # any copy this hook does not know about is stale from here on
     mine = {id(q) for group in optimizer.param_groups for q in group["params"] if q.requires_grad}
     srcs, dsts, rekey = [], [], []
@@ -139,8 +140,11 @@ def _after_optimizer_step(optimizer, args, kwargs):
             _CAST_REGISTRY.pop(key, None)
             continue
         old_key, dst = hit
-        if key[0] not in mine:                 # not updated by this optimizer: the copy is still right, only its key moves on
-            rekey.append((p, attr, old_key, dst))
+        if key[0] not in mine:                 # not updated by this optimizer: a copy that WAS current stays right, its key moves on
+            if old_key[:4] == (p._version, before, p.device, p.data_ptr()):
+                rekey.append((p, attr, old_key, dst))
+            else:                              # already stale (e.g. load_state_dict wrote the parameter): rebuilt on next use
+                _CAST_REGISTRY.pop(key, None)
             continue
         if attr == "_hvc_cast":
             srcs.append(p.detach())

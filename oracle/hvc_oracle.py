@@ -18,6 +18,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
 import torch.nn.functional as F
+import torch.utils.checkpoint
 
 Params = Dict[str, torch.Tensor]
 
@@ -25,6 +26,9 @@ Params = Dict[str, torch.Tensor]
 # ------------------------------------------------------------------------------------------------
 # attention  (models/vit_components.py)
 # ------------------------------------------------------------------------------------------------
+CHUNK_CHECKPOINT = False      # attention_core: checkpoint every q_chunk slab (set by the 128^3 fixture generator only)
+
+
 def attention_core(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float,
                    q_chunk: Optional[int] = None, p_drop: float = 0.0) -> torch.Tensor:
     """softmax(q k^T * scale) v on (B, h, N, d) operands -- models/vit_components.py:46-51 and
@@ -35,10 +39,18 @@ def attention_core(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: flo
     if q_chunk is None or q.shape[-2] <= q_chunk:
         attn = (q @ k.transpose(-2, -1)) * scale
         return F.dropout(attn.softmax(dim=-1), p_drop, p_drop > 0) @ v
+
+    def rows(qs, k_, v_):
+        return F.dropout(((qs @ k_.transpose(-2, -1)) * scale).softmax(dim=-1), p_drop, p_drop > 0) @ v_
     outs = []
     for s in range(0, q.shape[-2], q_chunk):
         qs = q[..., s:s + q_chunk, :]
-        outs.append(F.dropout(((qs @ k.transpose(-2, -1)) * scale).softmax(dim=-1), p_drop, p_drop > 0) @ v)
+        if CHUNK_CHECKPOINT and p_drop == 0 and torch.is_grad_enabled():
+            # same arithmetic, but the (chunk x N) probabilities are rebuilt in the backward pass instead of being kept:
+            # a fp32 backward at N = 32768 (128^3) then fits in tens of GB (tests/golden/make_direct128_probes.py)
+            outs.append(torch.utils.checkpoint.checkpoint(rows, qs, k, v, use_reentrant=False))
+        else:
+            outs.append(rows(qs, k, v))
     return torch.cat(outs, dim=-2)
 
 
@@ -288,12 +300,12 @@ def drr_reprojection_loss(pred: torch.Tensor, xrays: torch.Tensor, img_size: int
 def direct_ct_regression(xrays: torch.Tensor, P: Params, volume_size=(64, 64, 64), voxel_dim=256,
                          vit_depth=4, num_heads=4, training: bool = False,
                          new_stats: Optional[Params] = None, token_grid: Optional[int] = None,
-                         q_chunk: Optional[int] = None, p_drop: float = 0.0) -> torch.Tensor:
+                         q_chunk: Optional[int] = None, p_drop: float = 0.0, route: Optional[dict] = None) -> torch.Tensor:
     """DirectCTRegression.forward, direct_regression/model_direct.py:59-85 (p_drop = 0.1 with training=True is the
     reference's train mode: hybrid_vit_backbone.py:38, :166 hard-code dropout 0.1)."""
     B = xrays.shape[0]
     t = torch.zeros(B, 256, dtype=xrays.dtype, device=xrays.device)                            # :69
-    _, cond, feats = xray_conditioning(xrays, t, P, "xray_encoder.", training, new_stats)      # :72
+    _, cond, feats = xray_conditioning(xrays, t, P, "xray_encoder.", training, new_stats, route)   # :72 (route: see _relu_pool)
     x = P["initial_volume"].expand(B, -1, -1, -1, -1)                                          # :75
     ctx = feats.flatten(2).transpose(1, 2)                                                     # :80
     return hybrid_vit3d(x, ctx, cond, P, "vit_backbone.", volume_size, 1, voxel_dim, vit_depth,

@@ -34,6 +34,15 @@ def probe_indices(n):
     return np.random.default_rng(12345).integers(0, n, size=PROBE_N)
 
 
+def _report(key, metric, err, tol):
+    """HVC_TEST_REPORT=<file>: append every golden comparison's measured error and bound (how much margin a tolerance has)."""
+    path = os.environ.get("HVC_TEST_REPORT")
+    if path:
+        test = os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0].split("::")[-1]
+        with open(path, "a") as f:
+            f.write(f"{test}\t{key}\t{metric}\t{err:.3e}\t{tol:.1e}\n")
+
+
 class Golden:
     """Read access to one golden .npz (see tests/golden/make_golden.py for the layout)."""
 
@@ -76,6 +85,7 @@ class Golden:
             ref = self.z[key].astype(np.float64)
             assert ref.shape == v.shape, f"{key}: shape {v.shape} vs golden {ref.shape}"
             err = self._err(v, ref, metric)
+            _report(key, metric, err, tol)
             assert err <= tol, f"{key}: {metric} err {err:.3e} > {tol:.1e}"
             return err
         ref = self.z[key + "#probe"].astype(np.float64)
@@ -83,6 +93,7 @@ class Golden:
         assert v.size == int(stats[2]), f"{key}: size mismatch"
         got = v.reshape(-1)[probe_indices(v.size)]
         err = self._err(got, ref, metric)
+        _report(key + "#probe", metric, err, tol)
         assert err <= tol, f"{key} (probe): {metric} err {err:.3e} > {tol:.1e}"
         # stats[1] = sum |x| bounds the rounding of the plain sum
         assert abs(v.sum() - stats[0]) <= 10 * tol * stats[1] + 1e-12, f"{key}: checksum mismatch"

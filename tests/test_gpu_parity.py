@@ -151,9 +151,9 @@ def test_hybrid_vit3d_vs_golden(golden, tag, mode):
     g.check("", "out", y, _tol(mode), metric=_metric(mode))
     (y.float() * g.t("w").to(dev())).sum().backward()
     for k, t in (("x", x), ("ctx", ctx), ("cond", cond)):
-        g.check("igrad", k, t.grad, _tol(mode), 2, metric=_metric(mode))
+        g.check("igrad", k, t.grad, _tol(mode), metric=_metric(mode))
     for k, p in m.named_parameters():
-        g.check("pgrad", k, p.grad, _tol(mode), 2, metric=_metric(mode))
+        g.check("pgrad", k, p.grad, _tol(mode), metric=_metric(mode))
 
 
 def _hip_routing(records):
@@ -178,6 +178,51 @@ def _hip_routing(records):
     return route
 
 
+def _capture_stem_routing(monkeypatch):
+    """Records the operands of every hvc_bn_relu_pool_fwd call (-> _hip_routing): the ReLU gates and max-pool arg-max
+    choices the HIP X-ray stem really used."""
+    from hvc import ops
+    records = []
+    real_fwd = ops.bn_relu_pool_fwd
+
+    def capture(x, gamma, beta, running_mean, running_var, pool, training, *a, **kw):
+        y, amax, stats = real_fwd(x, gamma, beta, running_mean, running_var, pool, training, *a, **kw)
+        records.append((x.detach().clone(), None if amax is None else amax.clone(), stats.clone(), gamma.detach().clone(),
+                        beta.detach().clone(), pool))
+        return y, amax, stats
+    monkeypatch.setattr(ops, "bn_relu_pool_fwd", capture)
+    return records
+
+
+def _routing_agreement(route, hip_route):
+    """Fraction check of the routing-aware method: the HIP stem's routing differs from the oracle's own in < 1e-3 of the live
+    pool windows and ReLU gates (route["own"] is filled by the oracle evaluation that USED hip_route)."""
+    live = flipped = acts = act_flips = 0
+    for tag, own in route["own"].items():
+        acts += own["relu"].numel()
+        act_flips += int((own["relu"] != hip_route[tag]["relu"]).sum())
+        if "argmax" in own:
+            alive = own["max"] > 0                      # windows whose maximum survives the ReLU carry gradient
+            live += int(alive.sum())
+            flipped += int(((own["argmax"] != hip_route[tag]["argmax"]) & alive).sum())
+    assert flipped < 1e-3 * live and act_flips < 1e-3 * acts, (flipped, live, act_flips, acts)
+    return flipped, live, act_flips, acts
+
+
+def _maxrel(got, ref):
+    return ((got.detach().double().cpu() - ref.detach().double().cpu()).abs().max() / ref.detach().abs().max().clamp_min(1e-6)).item()
+
+
+def _note(key, err, tol, metric="max"):
+    """Same report line as conftest.Golden.check writes (HVC_TEST_REPORT), for comparisons made against the oracle directly."""
+    import os
+    path = os.environ.get("HVC_TEST_REPORT")
+    if path:
+        test = os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0].split("::")[-1]
+        with open(path, "a") as f:
+            f.write(f"{test}\t{key}\t{metric}\t{err:.3e}\t{tol:.1e}\n")
+
+
 @pytest.mark.parametrize("train", [False, True])
 def test_xray_conditioning_vs_golden(golden, train, monkeypatch):
     """Outputs vs the reference's golden vectors at 1e-3; gradients that do NOT pass the ReLU / max-pool routing at 1e-3.
@@ -194,15 +239,7 @@ def test_xray_conditioning_vs_golden(golden, train, monkeypatch):
     mode = "train" if train else "eval"
     m = XrayConditioningModule(img_size=S, in_channels=1, embed_dim=E, num_views=V, time_embed_dim=T, cond_dim=cond_dim)
     _load(m, g.group(f"{mode}_params")).train(train)
-    records = []
-    real_fwd = ops.bn_relu_pool_fwd
-
-    def capture(x, gamma, beta, running_mean, running_var, pool, training, *a, **kw):
-        y, amax, stats = real_fwd(x, gamma, beta, running_mean, running_var, pool, training, *a, **kw)
-        records.append((x.detach().clone(), None if amax is None else amax.clone(), stats.clone(), gamma.detach().clone(),
-                        beta.detach().clone(), pool))
-        return y, amax, stats
-    monkeypatch.setattr(ops, "bn_relu_pool_fwd", capture)
+    records = _capture_stem_routing(monkeypatch)
     xr, t = g.t("xrays").to(dev()).requires_grad_(True), g.t("t").to(dev()).requires_grad_(True)
     ctx, cond, feats = m(xr, t)
     assert len(records) == 3
@@ -214,7 +251,7 @@ def test_xray_conditioning_vs_golden(golden, train, monkeypatch):
     g.check("", f"{mode}_dt", t.grad, F32_TOL)
     for k, p in m.named_parameters():
         if not k.startswith("encoder."):
-            g.check(f"{mode}_pgrad", k, p.grad, F32_TOL, 5)
+            g.check(f"{mode}_pgrad", k, p.grad, F32_TOL)
     if train:
         for k, v in m.state_dict().items():
             if "running" in k:
@@ -226,23 +263,15 @@ def test_xray_conditioning_vs_golden(golden, train, monkeypatch):
     route = {"use": hip_route}
     c2, d2, f2 = O.xray_conditioning(xr_c, g.t("t"), P, "", train, {}, route)
     ((c2 * w_ctx).sum() + (d2 * w_cond).sum() + (f2 * w_f).sum()).backward()
-    live = flipped = acts = act_flips = 0
-    for tag, own in route["own"].items():
-        acts += own["relu"].numel()
-        act_flips += int((own["relu"] != hip_route[tag]["relu"]).sum())
-        if "argmax" in own:
-            alive = own["max"] > 0                      # windows whose maximum survives the ReLU carry gradient
-            live += int(alive.sum())
-            flipped += int(((own["argmax"] != hip_route[tag]["argmax"]) & alive).sum())
-    assert flipped < 1e-3 * live and act_flips < 1e-3 * acts, (flipped, live, act_flips, acts)
-    def rel(got, ref):
-        return ((got.detach().cpu() - ref).abs().max() / ref.abs().max().clamp_min(1e-6)).item()
-    assert rel(xr.grad, xr_c.grad) < F32_TOL, rel(xr.grad, xr_c.grad)
+    flipped, live, act_flips, acts = _routing_agreement(route, hip_route)
+    _note(f"{mode}_dxr(routed)", _maxrel(xr.grad, xr_c.grad), F32_TOL)
+    assert _maxrel(xr.grad, xr_c.grad) < F32_TOL, _maxrel(xr.grad, xr_c.grad)
     for k, p in m.named_parameters():
         if k.startswith("encoder."):
             if train and k.endswith(("encoder.0.bias", "encoder.4.bias", "encoder.8.bias")):
                 continue   # exactly-zero gradients (bias ahead of train-mode BN): rounding noise only
-            assert rel(p.grad, P[k].grad) < 2 * F32_TOL, (k, rel(p.grad, P[k].grad))
+            _note(f"{mode}_pgrad(routed)/{k}", _maxrel(p.grad, P[k].grad), F32_TOL)
+            assert _maxrel(p.grad, P[k].grad) < F32_TOL, (k, _maxrel(p.grad, P[k].grad))
     print(f"xray stem routing [{mode}]: {flipped}/{live} live pool windows and {act_flips}/{acts} ReLU gates resolved differently")
 
 
@@ -266,9 +295,26 @@ def test_drr_vs_golden_and_known_answers(golden):
     g.check("", "proj_dvol", v.grad, 1e-4)
 
 
+# Tolerance policy of the model-level tests below.  fp32 mode: max|got - ref| <= 1e-3 max|ref| for EVERY tensor, no multipliers.
+# Tensors behind the X-ray stem's ReLU / max-pool routing (X-ray pixel gradients, encoder.* parameters) are compared with the
+# oracle evaluated WITH the routing the HIP stem used (a near-tie that rounds the other way re-routes a whole window, which no
+# tolerance can absorb): same 1e-3, plus < 1e-3 of the routing decisions may differ.  bf16 mode (the trainers' autocast): relative
+# Frobenius error <= 4e-2; routed tensors in bf16 are only held to a norm bound of 0.4 - the bf16 stem resolves ~1 % of its
+# near-ties differently and fp32 mode is the parity statement for them.
+_ROUTED_BF16_TOL = 0.4
+# bf16 mode, parameter / input gradients of whole models: gradients formed by cancellation over thousands of bf16 products
+# (pos_embed, first-layer conv weights, GroupNorm affine parameters) sit at 5e-2 .. 1.2e-1 relative Frobenius error against the
+# fp32 reference - the CPU oracle under autocast(bf16) misses them by as much; outputs keep 4e-2.
+_BF16_GRAD_TOL = 1.5e-1
+
+
+def _gtol(mode):
+    return F32_TOL if mode == "f32" else _BF16_GRAD_TOL
+
+
 @pytest.mark.parametrize("mode", ["f32", "bf16"])
 @pytest.mark.parametrize("train", [False, True])
-def test_direct_regression_small_vs_golden(golden, train, mode):
+def test_direct_regression_small_vs_golden(golden, train, mode, monkeypatch):
     from direct_regression.model_direct import DirectCTRegression, DirectRegressionLoss
     g = golden("direct_small")
     cfg = [int(v) for v in g.z["cfg"]]
@@ -281,24 +327,45 @@ def test_direct_regression_small_vs_golden(golden, train, mode):
     xr = g.t("xrays").to(dev()).requires_grad_(True)
     target = g.t("target").to(dev())
     crit = DirectRegressionLoss(1.0, 0.5)
+    records = _capture_stem_routing(monkeypatch)
 
     def step():
         pred = m(xr)
         return pred, crit(pred.float(), target)
     pred, losses = _run(mode, step)
     tol = _tol(mode)
-    g.check("", f"{tag}_pred", pred, tol, 2, metric=_metric(mode))
+    g.check("", f"{tag}_pred", pred, tol, metric=_metric(mode))
     ref = g.z[f"{tag}_loss"]
     got = [losses[k].item() for k in ("total_loss", "l1_loss", "ssim_loss")]
-    assert np.allclose(got, ref, rtol=5 * tol), (got, ref)
+    assert np.allclose(got, ref, rtol=tol), (got, ref)
     from oracle import hvc_oracle as O
     assert abs(O.psnr(pred.detach().float().cpu(), target.cpu()) - float(g.z[f"{tag}_psnr"])) < 0.1   # dB
     losses["total_loss"].backward()
-    g.check("", f"{tag}_dxr", xr.grad, max(tol, 3e-3), 10, metric="l2")    # max-pool near-ties: see the X-ray stem test
+    routed = lambda k: k.startswith("xray_encoder.encoder.")
     for k, p in m.named_parameters():
         if train and k.endswith(("encoder.0.bias", "encoder.4.bias", "encoder.8.bias")):
-            continue
-        g.check(f"{tag}_pgrad", k, p.grad, tol, 10, metric=_metric(mode))
+            continue                       # exactly-zero gradients (bias ahead of train-mode BN): rounding noise only
+        if not routed(k):
+            g.check(f"{tag}_pgrad", k, p.grad, _gtol(mode), metric=_metric(mode))
+        elif mode == "bf16":
+            g.check(f"{tag}_pgrad", k, p.grad, _ROUTED_BF16_TOL, metric="l2")
+    if mode == "bf16":
+        g.check("", f"{tag}_dxr", xr.grad, _ROUTED_BF16_TOL, metric="l2")
+        return
+    # fp32 mode, routed tensors: the oracle evaluated with the routing the HIP stem used
+    hip_route = _hip_routing(records)
+    P = {k: v.clone().requires_grad_(v.dtype.is_floating_point and "running_" not in k) for k, v in g.group("params").items()}
+    xr_c = g.t("xrays").requires_grad_(True)
+    route = {"use": hip_route}
+    pred_c = O.direct_ct_regression(xr_c, P, tuple(cfg[:3]), cfg[4], cfg[5], cfg[6], training=train, new_stats={}, route=route)
+    O.direct_regression_loss(pred_c, g.t("target"))["total_loss"].backward()
+    _routing_agreement(route, hip_route)
+    _note(f"{tag}_dxr(routed)", _maxrel(xr.grad, xr_c.grad), tol)
+    assert _maxrel(xr.grad, xr_c.grad) < tol, _maxrel(xr.grad, xr_c.grad)
+    for k, p in m.named_parameters():
+        if routed(k) and not (train and k.endswith(("encoder.0.bias", "encoder.4.bias", "encoder.8.bias"))):
+            _note(f"{tag}_pgrad(routed)/{k}", _maxrel(p.grad, P[k].grad), tol)
+            assert _maxrel(p.grad, P[k].grad) < tol, (k, _maxrel(p.grad, P[k].grad))
 
 
 # ----------------------------------------------------------------------------------------------
@@ -908,19 +975,21 @@ def test_cascade_refiners_vs_golden(golden, mode):
         return f1, f2, v32, s3(v32, f3, cond3)
     f1, f2, v32, v64 = _run(mode, run)
     tol, met = _tol(mode), _metric(mode)
-    g.check("", "feats1", f1, tol, 5, metric=met)
-    g.check("", "feats2", f2, tol, 5, metric=met)
-    g.check("", "v32", v32, tol, 5, metric=met)
-    g.check("", "v64", v64, tol, 5, metric=met)
+    g.check("", "feats1", f1, tol, metric=met)
+    g.check("", "feats2", f2, tol, metric=met)
+    g.check("", "v32", v32, tol, metric=met)
+    g.check("", "v64", v64, tol, metric=met)
     ((v32.float() * g.t("w2").to(dev())).sum() + (v64.float() * g.t("w3").to(dev())).sum() + f1.float().sum() * 0.1).backward()
-    g.check("", "dv16", v16.grad, max(tol, 3e-3), 10, metric="l2")
+    g.check("", "dv16", v16.grad, _gtol(mode), metric=met)
     for pre, m in (("enc", enc), ("s2", s2), ("s3", s3)):
         for k, p in m.named_parameters():
             if p.grad is None:
                 continue
             if k in _zero_grad_biases(m):
                 continue   # conv bias ahead of a one-channel-per-group GroupNorm: exactly-zero gradient, rounding noise only
-            g.check(f"{pre}_pgrad", k, p.grad, max(tol, 3e-3), 10, metric="l2")    # ReLU / max-pool routing upstream: norm metric
+            # encoder parameters sit behind the stem's ReLU / max-pool routing; on this fixture (eval mode) the HIP and the
+            # reference routings agree on every live window in fp32 mode, so they hold the flat 1e-3 like everything else
+            g.check(f"{pre}_pgrad", k, p.grad, _gtol(mode), metric=met)
 
 
 def test_stage3_gradient_checkpointing_replays_dropout_masks():
@@ -1458,11 +1527,11 @@ def test_bench_launches_its_own_ranks(tmp_path):
 # round-2 parity additions ("close the parity holes")
 # ----------------------------------------------------------------------------------------------
 @pytest.mark.timeout(900)
-def test_direct_model_full_size_64_forward_and_backward_vs_oracle():
+def test_direct_model_full_size_64_forward_and_backward_vs_oracle(monkeypatch):
     """BASELINE config #1/#2 geometry (64^3, 2-view 512^2, 4096 + 4096 tokens): forward AND backward of the whole model
     + DirectRegressionLoss against the CPU oracle on identical weights / inputs, fp32 mode, 1e-3 max-rel per tensor.
-    Eval mode (running BN statistics; dropout is off in eval).  X-ray pixels / stem weights sit behind ReLU + max-pool
-    routing (see test_xray_conditioning_vs_golden) and are compared in norm here."""
+    Eval mode (running BN statistics; dropout is off in eval).  The stem weights sit behind ReLU + max-pool routing: the
+    oracle is evaluated with the routing the HIP stem used (see test_xray_conditioning_vs_golden)."""
     from direct_regression.model_direct import DirectCTRegression, DirectRegressionLoss
     from hvc import synthetic
     from oracle import hvc_oracle as O
@@ -1477,14 +1546,20 @@ def test_direct_model_full_size_64_forward_and_backward_vs_oracle():
     xr, ct = xr[None], ct[None]
     P = {k: v.detach().clone().requires_grad_(v.dtype.is_floating_point and "running_" not in k) for k, v in m.state_dict().items()}
     torch.set_num_threads(min(16, torch.get_num_threads() or 16))
-    ref = O.direct_ct_regression(xr, P)
-    ref_loss = O.direct_regression_loss(ref, ct)
-    ref_loss["total_loss"].backward()
+    records = _capture_stem_routing(monkeypatch)
     m.to(dev())
     pred = m(xr.to(dev()))
     loss = DirectRegressionLoss(1.0, 0.5)(pred, ct.to(dev()))
     loss["total_loss"].backward()
-    assert ((pred.detach().cpu() - ref.detach()).abs().max() / ref.detach().abs().max()).item() < F32_TOL
+    # the oracle, evaluated with the routing the HIP stem used (identical function wherever the two routings agree - and they
+    # must agree on all but < 1e-3 of the live windows / gates): every tensor, routed or not, then holds the flat 1e-3
+    hip_route = _hip_routing(records)
+    route = {"use": hip_route}
+    ref = O.direct_ct_regression(xr, P, route=route)
+    ref_loss = O.direct_regression_loss(ref, ct)
+    ref_loss["total_loss"].backward()
+    _routing_agreement(route, hip_route)
+    assert _maxrel(pred, ref) < F32_TOL
     for k in ("total_loss", "l1_loss", "ssim_loss"):
         assert abs(loss[k].item() - ref_loss[k].item()) < F32_TOL * abs(ref_loss[k].item()) + 1e-6, k
     worst = {}
@@ -1492,14 +1567,76 @@ def test_direct_model_full_size_64_forward_and_backward_vs_oracle():
         r = P[k].grad
         if r.abs().max() < 1e-9:
             continue
-        if k.startswith("xray_encoder.encoder."):
-            err = ((p.grad.cpu() - r).norm() / r.norm()).item()
-            assert err < 3e-2, (k, err)
-        else:
-            err = ((p.grad.cpu() - r).abs().max() / r.abs().max()).item()
-            assert err < F32_TOL, (k, err)
+        err = _maxrel(p.grad, r)
+        _note(f"pgrad/{k}", err, F32_TOL)
+        assert err < F32_TOL, (k, err)
         worst[k] = err
-    print("64^3 fwd+bwd vs oracle: worst", max(worst.items(), key=lambda kv: kv[1] if not kv[0].startswith("xray_encoder.encoder.") else 0))
+    print("64^3 fwd+bwd vs oracle: worst", max(worst.items(), key=lambda kv: kv[1]))
+
+
+@pytest.mark.timeout(900)
+def test_direct_model_128_forward_and_backward_vs_oracle_probes(golden, monkeypatch):
+    """The headline workload's model (DirectCTRegression at 128^3 = 32768 tokens, BASELINE config #3 geometry, B = 1) in fp32 mode:
+    loss, output volume and EVERY parameter gradient against tests/golden/direct128_probes.npz at 1e-3.  The fixture is
+    ORACLE-generated (tests/golden/make_direct128_probes.py: the reference raises at 128^3, hybrid_vit_backbone.py:178-188, so
+    only the oracle - pinned to the reference by the other fixtures at N <= 4096 - can say what this model computes): 512 probes +
+    checksums per large tensor.  X-ray stem gradients (behind its ReLU / max-pool routing) by the routing-aware method: the
+    upstream gradients d loss / d features and d loss / d cond are compared with the fixture, then pushed through the oracle stem
+    evaluated with the routing the HIP stem used."""
+    from direct_regression.model_direct import DirectCTRegression, DirectRegressionLoss
+    from hvc import synthetic
+    from oracle import hvc_oracle as O
+    g = golden("direct128_probes")
+    vol = (128, 128, 128)
+    torch.manual_seed(0)
+    m = DirectCTRegression(volume_size=vol).eval()
+    gen = torch.Generator().manual_seed(31)
+    with torch.no_grad():
+        for blk in m.vit_backbone.blocks:
+            blk.adaln.linear.weight.copy_(torch.randn(blk.adaln.linear.weight.shape, generator=gen) * 0.02)
+            blk.adaln.linear.bias.copy_(torch.randn(blk.adaln.linear.bias.shape, generator=gen) * 0.02)
+    state = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    chk = np.array([sum(float(v.double().sum()) for v in state.values() if v.dtype.is_floating_point),
+                    sum(float(v.double().abs().sum()) for v in state.values() if v.dtype.is_floating_point)])
+    assert np.allclose(chk, g.z["weights_checksum"], rtol=1e-9), "the seeded weights differ from the ones the fixture was made with"
+    xr, ct = synthetic.sample(3, vol, 512)
+    xr, ct = xr[None], ct[None]
+    records = _capture_stem_routing(monkeypatch)
+    m.to(dev())
+    # DirectCTRegression.forward (model_direct.py:59-85) step by step, to keep handles on the stem's outputs
+    xd = xr.to(dev())
+    t = torch.zeros(1, 256, device=dev())
+    _, cond, feats = m.xray_encoder(xd, t)
+    cond.retain_grad()
+    feats.retain_grad()
+    pred = m.vit_backbone(m.initial_volume.expand(1, -1, -1, -1, -1), feats.flatten(2).transpose(1, 2), cond)
+    with torch.no_grad():
+        assert torch.equal(pred, m(xd))                                   # the same function as the module's own forward
+    loss = DirectRegressionLoss(1.0, 0.5)(pred, ct.to(dev()))
+    loss["total_loss"].backward()
+    for k in ("total_loss", "l1_loss", "ssim_loss"):
+        assert abs(loss[k].item() - float(g.z["loss/" + k])) < F32_TOL * abs(float(g.z["loss/" + k])), k
+    g.check("out", "pred", pred, F32_TOL)
+    # gradients arriving at the stem's two outputs: through the cross-attention context (the HIP module's `feats` output feeds
+    # nothing else; its pooled sibling feeds cond) and through the conditioning vector
+    g.check("xgrad", "ctx", feats.grad.flatten(2).transpose(1, 2), F32_TOL)
+    g.check("xgrad", "cond", cond.grad, F32_TOL)
+    routed = lambda k: k.startswith("xray_encoder.encoder.")
+    for k, p in m.named_parameters():
+        if not routed(k):
+            g.check("pgrad", k, p.grad, F32_TOL)
+    # stem: oracle with the HIP routing, fed with the HIP path's own upstream gradients (just checked against the fixture)
+    hip_route = _hip_routing(records)
+    P = {k: v.clone().requires_grad_(v.dtype.is_floating_point and "running_" not in k) for k, v in state.items() if k.startswith("xray_encoder.")}
+    route = {"use": hip_route}
+    _, cond_c, feats_c = O.xray_conditioning(xr, torch.zeros(1, 256), P, "xray_encoder.", False, None, route)
+    _routing_agreement(route, hip_route)
+    assert _maxrel(feats, feats_c) < F32_TOL and _maxrel(cond, cond_c) < F32_TOL
+    torch.autograd.backward([feats_c, cond_c], [feats.grad.cpu(), cond.grad.cpu()])      # cond_c's own dependence on the features: autograd
+    for k, p in m.named_parameters():
+        if routed(k):
+            _note(f"pgrad(routed)/{k}", _maxrel(p.grad, P[k].grad), F32_TOL)
+            assert _maxrel(p.grad, P[k].grad) < F32_TOL, (k, _maxrel(p.grad, P[k].grad))
 
 
 def test_attention_full_size_128_dk_dv_rows_vs_fp64():
@@ -1715,6 +1852,7 @@ def test_train_step_vs_reference_fixture(golden, mode):
     tol = _tol(mode)
     lr = 1e-4
     routed = ("xray_encoder.encoder.",)                       # behind ReLU / max-pool routing: norm comparison (see the stem test)
+    resolvable = {}          # bf16 mode: per tensor, the elements whose reference gradient stood above the run's gradient error so far
     for step in (1, 2):
         before = {k: p.detach().clone() for k, p in m.named_parameters()}
         norms = []
@@ -1724,15 +1862,20 @@ def test_train_step_vs_reference_fixture(golden, mode):
             losses = T.train_step(m, crit, opt, None, xr, target, 1.0, autocast_dtype=None if mode == "f32" else torch.bfloat16)
         finally:
             torch.nn.utils.clip_grad_norm_ = real_clip
-        assert abs(losses["total_loss"].item() - float(g.z[f"step{step}_loss"])) < 5 * tol * float(g.z[f"step{step}_loss"])
+        assert abs(losses["total_loss"].item() - float(g.z[f"step{step}_loss"])) < tol * float(g.z[f"step{step}_loss"])
         ref_norm = float(g.z[f"step{step}_gradnorm"])
-        assert abs(norms[0].item() - ref_norm) < 10 * tol * ref_norm, (norms[0].item(), ref_norm)
+        assert abs(norms[0].item() - ref_norm) < tol * ref_norm, (norms[0].item(), ref_norm)
         moved_badly = {}
         for k, p in m.named_parameters():
             if k.endswith(("encoder.0.bias", "encoder.4.bias", "encoder.8.bias")):
                 continue                                     # zero-gradient biases ahead of train-mode BN: both sides hold noise
-            metric = "l2" if (mode == "bf16" or k.startswith(routed)) else "max"
-            g.check(f"step{step}_clipped", k, p.grad, max(tol, 3e-2) if k.startswith(routed) else tol, 10, metric=metric)
+            if mode == "f32":
+                # flat 1e-3; routed tensors (behind the stem's ReLU / max-pool choices) in the Frobenius norm: this is a REFERENCE
+                # fixture, the reference's own routing cannot be replaced by the HIP one, and a single window that resolves a
+                # near-tie the other way moves one element by O(1) while leaving the norm at the 1e-4 level
+                g.check(f"step{step}_clipped", k, p.grad, tol, metric="l2" if k.startswith(routed) else "max")
+            else:
+                g.check(f"step{step}_clipped", k, p.grad, _ROUTED_BF16_TOL if k.startswith(routed) else _gtol(mode), metric="l2")
             # AdamW moves every weight by <= ~lr per step whatever the gradient's size (step 1 is sign-like: -lr g / (|g| + eps)
             # - lr wd w), so weights are compared by how far they MOVED from the initial fixture weights, in units of lr: even the
             # bf16 run must land on the reference's weights except where a tiny gradient's sign is decided by rounding
@@ -1743,14 +1886,30 @@ def test_train_step_vs_reference_fixture(golden, mode):
             diff = np.abs(got_move - ref_move)
             assert diff.max() <= 2.1 * lr * step, (k, diff.max() / lr)
             moved_badly[k] = float((diff > 0.3 * lr).mean())
-            # bf16: gradients behind the ReLU / max-pool routing (X-ray stem) are the noisiest, and a sign-like update amplifies it
-            # (fp32 mode is the parity statement: <= 2 % of the weights; the bf16 run is a sanity bound on the same quantity)
-            bound = 0.02 if mode == "f32" else 0.40
-            assert moved_badly[k] <= bound, (k, moved_badly[k])
+            # fp32 mode is the parity statement: <= 2 % of the weights of EVERY tensor.
+            # bf16 mode: AdamW's first steps are sign-like, -lr g / (|g| + 1e-8): a weight can only be expected to move as in the
+            # reference where its reference gradient is RESOLVED by this run, i.e. stands above the run's own gradient error (the
+            # norm of that error is bounded above: 0.15, routed 0.4).  So: per tensor, sigma = rms(g_hip - g_ref); among the
+            # elements with |g_ref| >= 5 sigma in every step so far, <= 2 % may move differently (and these elements must exist,
+            # unless the whole gradient is rounding noise); elements below the noise floor keep the 2.1 lr-per-step bound above.
+            if mode == "f32":
+                _note(f"step{step}_moved/{k}", moved_badly[k], 0.02, "moved>0.3lr")
+                assert moved_badly[k] <= 0.02, (k, moved_badly[k])
+            else:
+                gref, gpick = g.ref_values(f"step{step}_clipped", k)
+                ggot = gpick(p.grad.detach().double().cpu().numpy())
+                sigma = float(np.sqrt(np.mean((ggot - gref) ** 2)))
+                ok = np.abs(gref) >= 5 * sigma
+                resolvable[k] = ok if k not in resolvable else (resolvable[k] & ok)
+                nres = int(resolvable[k].sum())
+                bad = float((diff[resolvable[k]] > 0.3 * lr).mean()) if nres else 0.0
+                _note(f"step{step}_moved_resolved/{k}", bad, 0.02, f"moved>0.3lr among {nres}/{ok.size} resolved")
+                assert bad <= 0.02, (k, bad, nres)
+                assert nres >= 0.25 * ok.size or k.startswith(routed) or np.abs(gref).max() < 1e-7, (k, nres, ok.size)
         print(f"train_step [{mode}] step {step}: worst fraction of weights that moved differently (> 0.3 lr): {max(moved_badly.values()):.3%}")
     for k, v in m.state_dict().items():
         if "running_" in k:
-            g.check("step2_after", k, v, 10 * tol)
+            g.check("step2_after", k, v, tol if mode == "f32" else 10 * tol)      # bf16 conv outputs feed the batch statistics
 
 
 def test_sinusoidal_time_embedding_vs_golden(golden):

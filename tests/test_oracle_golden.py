@@ -285,3 +285,20 @@ def test_xray_encoder_explicit_routing_is_the_same_function(golden):
     for a, b in zip(*outs):
         assert torch.allclose(a, b, rtol=1e-6, atol=1e-7)
     g.check("", "train_dxr", outs[1][1], RTOL * 5)
+
+
+def test_direct128_probe_fixture_matches_the_seeded_model(golden):
+    """tests/golden/direct128_probes.npz (oracle-generated: the reference raises at 128^3) belongs to the model the GPU test
+    rebuilds: same seeded weights (checksum), one probe / full entry per parameter, finite values."""
+    import numpy as np
+    from tests.golden.make_direct128_probes import build_inputs, weight_checksum
+    g = golden("direct128_probes")
+    m, xr, ct = build_inputs()
+    assert np.allclose(weight_checksum(m.state_dict()), g.z["weights_checksum"], rtol=1e-9)
+    assert xr.shape == (1, 2, 1, 512, 512) and ct.shape == (1, 1, 128, 128, 128)
+    names = {k for k, p in m.named_parameters()}
+    assert names == set(g.keys("pgrad")), names ^ set(g.keys("pgrad"))
+    assert m.vit_backbone.pos_embed.shape[1] == 32 ** 3                       # the A2-fix geometry: 32^3 = 32768 tokens
+    for k in g.z.files:
+        assert np.isfinite(g.z[k]).all(), k
+    assert abs(float(g.z["loss/total_loss"]) - (float(g.z["loss/l1_loss"]) + 0.5 * float(g.z["loss/ssim_loss"]))) < 1e-6
