@@ -229,15 +229,28 @@ __global__ __launch_bounds__(256) void gn_silu_bwd_reduce_kernel(const T* __rest
     const int b = blockIdx.y, chunk = blockIdx.x, cg = C / G;
     const T* xb = x + (int64_t)b * P * C;
     const T* db = dy + (int64_t)b * P * C;
+    // a thread keeps its 8 channels for the whole sweep (column_sums: c8 = tid % (C/8)): statistics and affine parameters of
+    // those channels are fetched once, as xhat = x * rs + nm and z = xhat * gamma + beta
+    float rs[8], nm[8], gam[8], bet[8];
+    {
+        const int c8 = threadIdx.x % (C / 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = c8 * 8 + j, g = c / cg;
+            rs[j] = stats[2 * (b * G + g) + 1];
+            nm[j] = -stats[2 * (b * G + g)] * rs[j];
+            gam[j] = gamma[c];
+            bet[j] = beta[c];
+        }
+    }
     column_sums(P, C, chunk, nchunk, red, out, [&](int p, int c8, float (&u)[8], float (&v)[8]) {
         float xv[8], dv[8];
         load8<T>(xb + (int64_t)p * C + c8 * 8, xv);
         load8<T>(db + (int64_t)p * C + c8 * 8, dv);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int c = c8 * 8 + j, g = c / cg;
-            const float xh = (xv[j] - stats[2 * (b * G + g)]) * stats[2 * (b * G + g) + 1];
-            const float ds = dv[j] * act_grad_f(xh * gamma[c] + beta[c], act);
+            const float xh = fmaf(xv[j], rs[j], nm[j]);
+            const float ds = dv[j] * act_grad_f(fmaf(xh, gam[j], bet[j]), act);
             u[j] = ds;
             v[j] = ds * xh;
         }
@@ -494,11 +507,14 @@ int grid_for(int64_t work) {
 
 }  // namespace
 
+// Position slabs per image for the per-channel reductions.  Up to 1024: at batch 1 (cascade stage 3, 256^3 x 32 channels) the
+// old cap of 128 slabs put 128 workgroups on 256 CUs, one per CU - the reduce passes ran at half the chip with nothing to
+// hide their latency (gn_silu_bwd_reduce 1240 us, 1.7 TB/s); >= 2048 positions per slab keep the LDS fold negligible.
 int norm_chunks(int P) {
-    int n = (P + 255) / 256;
-    if (n > 128) n = 128;
-    if (n < 1) n = 1;
-    return n;
+    const int small = (P + 255) / 256 < 128 ? (P + 255) / 256 : 128;      // up to 32768 positions: 256 per slab; then 128 slabs ...
+    const int large = (P + 2047) / 2048 < 1024 ? (P + 2047) / 2048 : 1024; // ... until 2048 per slab gives more, up to 1024 slabs
+    const int n = small > large ? small : large;
+    return n < 1 ? 1 : n;
 }
 
 #define HVC_DISPATCH_T(is_bf16, CALL)            \
