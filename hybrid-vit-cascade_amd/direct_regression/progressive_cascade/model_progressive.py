@@ -131,7 +131,10 @@ class Stage3Refiner256(nn.Module):
     def forward(self, volume_128, xray_features_2d, time_xray_cond):
         cdt = HF.compute_dtype(volume_128)
         x = HS.glue_sequential(self.upsample_from_128, _volume_channels_last(volume_128), cdt)
-        if self.use_gradient_checkpointing and self.training:
+        # per token and block the branches keep ~48 C bytes (bf16 LN outputs, qkv / q / o / z, pre- and post-GELU, fp32 residuals)
+        vit = self.vit_refiner
+        saved = x.shape[0] * vit.pos_embed.shape[1] * len(vit.blocks) * 48 * vit.pos_embed.shape[2]
+        if self.training and HF.use_checkpoint(self.use_gradient_checkpointing, saved, x.device):
             refinement = torch.utils.checkpoint.checkpoint(self._vit_forward, x, xray_features_2d, time_xray_cond,
                                                            use_reentrant=False)
         else:

@@ -188,6 +188,8 @@ def train_stage(rank, world_size, config, stage, checkpoint_dir, synthetic=False
     device = torch.device("cuda", rank % max(torch.cuda.device_count(), 1))
     # "mi355x": {"fp8_attention": true} runs the attention forward's Q K^T / P V products as fp8 (e4m3) MFMAs (BASELINE configs[4])
     HF.set_fp8_attention(bool(config.get("mi355x", {}).get("fp8_attention", False)))
+    # "gradient_checkpointing": "auto" (default: recompute the stage-3 ViT only if its activations would not fit in HBM) | "on" | "off"
+    HF.set_checkpoint_policy(config.get("mi355x", {}).get("gradient_checkpointing", "auto"))
     model, criterion, optimizer, scheduler = build_stage(config, stage, checkpoint_dir, device, rank)
     ddp_model = wrap_ddp(model, [device.index]) if dist.is_initialized() else model
     scaler = torch.amp.GradScaler("cuda", enabled=False)      # bf16: no loss scaling; object kept for API parity

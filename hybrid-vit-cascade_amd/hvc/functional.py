@@ -25,6 +25,32 @@ def set_fp8_attention(on: bool) -> None:
     ATTN_FP8 = bool(on)
 
 
+# Gradient checkpointing of the cascade's stage-3 ViT (reference model_progressive.py:296-305 recomputes the refiner's forward in
+# the backward pass to fit 40-80 GB cards).  On MI355X the saved activations of that ViT (~4 GB at 256^3, batch 1) are noise
+# against 288 GB of HBM and the recomputation costs a sixth of the step, so the default policy honours the model's
+# use_gradient_checkpointing flag only when the activations would not fit comfortably ("auto"); "on" = whenever the model
+# asks (the reference's behaviour), "off" = never.  Results are identical either way (same dropout seeds are replayed).
+# Set from the "mi355x": {"gradient_checkpointing": ...} section of the JSON config, or by hand.
+CHECKPOINT_POLICY = "auto"
+
+
+def set_checkpoint_policy(policy: str) -> None:
+    global CHECKPOINT_POLICY
+    if policy not in ("auto", "on", "off"):
+        raise ValueError("checkpoint policy must be 'auto', 'on' or 'off'")
+    CHECKPOINT_POLICY = policy
+
+
+def use_checkpoint(requested: bool, saved_bytes: int, device) -> bool:
+    """Should a module that was asked to checkpoint (requested) really recompute?  saved_bytes = what it would keep otherwise."""
+    if not requested or CHECKPOINT_POLICY == "off":
+        return False
+    if CHECKPOINT_POLICY == "on" or not torch.cuda.is_available():
+        return True
+    free, _total = torch.cuda.mem_get_info(device)
+    return 4 * saved_bytes > free          # auto: recompute only if four times the saved activations would not fit
+
+
 def _fp8(t) -> bool:
     """fp8 forward for this operand?  Only bf16 operands with a head dim the fp8 kernel is built for (32 / 64: the cascade's and
     the direct model's heads); anything else keeps the bf16 kernel."""

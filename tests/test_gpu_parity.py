@@ -992,11 +992,13 @@ def test_cascade_refiners_vs_golden(golden, mode):
             g.check(f"{pre}_pgrad", k, p.grad, _gtol(mode), metric=met)
 
 
-def test_stage3_gradient_checkpointing_replays_dropout_masks():
+def test_stage3_gradient_checkpointing_replays_dropout_masks(monkeypatch):
     """BASELINE config #5 trains stage 3 with gradient checkpointing (model_progressive.py:296-305).  The recomputation
     must redraw the same counter-based dropout seeds (torch.utils.checkpoint restores the CPU generator they come
     from): gradients with and without checkpointing are then bitwise equal in train mode with dropout 0.1."""
     from direct_regression.progressive_cascade.model_progressive import Stage3Refiner256
+    from hvc import functional as HF
+    monkeypatch.setattr(HF, "CHECKPOINT_POLICY", "on")      # the default "auto" skips the recomputation while HBM has room: force the path under test
     torch.manual_seed(5)
     ref = Stage3Refiner256(volume_size=(32, 32, 32), voxel_dim=64, vit_depth=2, num_heads=2, xray_feature_dim=32,
                            use_gradient_checkpointing=False).to(dev()).train()
@@ -1713,14 +1715,17 @@ def test_direct_model_full_size_128_forward_backward_batch2():
 
 
 @pytest.mark.timeout(1100)
-@pytest.mark.parametrize("fp8", [False, True], ids=["bf16_attention", "fp8_attention"])
-def test_progressive_trainer_stage3_256_full_losses_with_checkpointing(tmp_path, fp8):
+@pytest.mark.parametrize("fp8,policy", [(False, "on"), (True, "on"), (False, "auto")],
+                         ids=["bf16_attention", "fp8_attention", "bf16_attention_auto_policy"])
+def test_progressive_trainer_stage3_256_full_losses_with_checkpointing(tmp_path, fp8, policy):
     """BASELINE config #5 as a test (per-GPU slice, batch 1; with the "mi355x": {"fp8_attention": true} switch the attention
     forward products run as e4m3 MFMAs, as the config names): one optimisation step of cascade stage 3 at 256^3 through
     train_progressive_4gpu.build_stage / train_step with gradient checkpointing (reference model_progressive.py:286-291,
     train_progressive_4gpu.py:214-219) and the full Stage3Loss (L1 + SSIM + TV + frequency + 0.3 DRR reprojection,
     loss_multiscale.py:384-432; the VGG term needs downloaded weights and is skipped with a notice).  Stages 1 and 2 are
-    frozen: no gradients, weights untouched; stage 3 and its X-ray head move; every loss term is finite."""
+    frozen: no gradients, weights untouched; stage 3 and its X-ray head move; every loss term is finite.
+    policy "on" = the reference's behaviour (recompute the ViT in the backward pass); "auto" = the MI355X default, which keeps the
+    ~4 GB of activations instead while HBM has room (hvc.functional.use_checkpoint) - same step, no recomputation."""
     import copy, json, os, sys
     here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, os.path.join(here, "hybrid-vit-cascade_amd", "direct_regression"))
@@ -1735,10 +1740,12 @@ def test_progressive_trainer_stage3_256_full_losses_with_checkpointing(tmp_path,
     from hvc import functional as HF
     cfg.setdefault("mi355x", {})["fp8_attention"] = fp8
     HF.set_fp8_attention(bool(cfg["mi355x"]["fp8_attention"]))            # what train_stage does with the config section
+    HF.set_checkpoint_policy(policy)
     try:
         _stage3_256_step(T, cfg, tmp_path, synthetic, fp8)
     finally:
         HF.set_fp8_attention(False)
+        HF.set_checkpoint_policy("auto")
 
 
 def _stage3_256_step(T, cfg, tmp_path, synthetic, fp8):
