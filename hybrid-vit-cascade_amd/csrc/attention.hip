@@ -60,26 +60,70 @@ __device__ __forceinline__ Chunk8<T> load_row_chunk(const T* base, int64_t sn, i
     }
 }
 
+// Tile staging, two forms.
+//  * register staged (fp32 operands, unaligned / ragged-stride operands): global loads into registers one tile ahead, ds_write_b128
+//    into the swizzled image at the end of the tile.
+//  * LDS-DMA (bf16 operands with 16-byte addressable rows; HVC_ATTN_DMA=0 at build time pins the register form): the tile goes
+//    from global memory straight into the LDS image with global_load_lds_dwordx4 - no staging registers, no ds_write_b128 (whose
+//    13 cycles each on the LDS store path were, with the loads, 8 - 14 % of the dK/dV kernel: profiles/r03_attention_*).  One
+//    wave-instruction writes 64 lanes x 16 bytes CONTIGUOUSLY (1 KiB = 8 or 16 tile rows), so the image's XOR swizzle moves to
+//    the source side: the lane that fills physical slot s of row r fetches logical chunk s ^ sw(r) of that row (an involution;
+//    the eight / four lanes of a row still cover its whole 128 / 64 bytes, so global coalescing is unchanged).  Rows past the end
+//    of the operand are clamped to its last row (finite values; their probabilities are zero either way).  Nothing tracks a
+//    DMA's arrival but the issuing wave's vmcnt: wait() before the barrier that ends the tile.
+#ifndef HVC_ATTN_DMA
+#define HVC_ATTN_DMA 1
+#endif
+// One LDS-DMA piece: 64 lanes x 16 bytes from per-lane global addresses to the 1 KiB at the wave-uniform LDS address dst.
+// Inline asm on purpose: issued through __builtin_amdgcn_global_load_lds, hipcc puts an s_waitcnt vmcnt(0) in front of the next
+// LDS read that it cannot prove disjoint from the piece - i.e. in the middle of the tile, where it exposes the whole load latency.
+// As an asm statement the piece is invisible to that bookkeeping (its arrival is ours to wait for: TileLoader::wait()); the
+// compiler's own vmcnt(N) waits stay correct, they can only wait for more than they meant to.  M0 (the LDS base of the piece) is
+// compiler-reserved: saved, written and restored inside the one statement, with the wait state its reader needs.
+__device__ __forceinline__ void lds_dma16(const void* src, const bf16* dst) {
+    const uint32_t lds_addr = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)dst);      // generic -> LDS offset: the low word
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(src), "s"(lds_addr) : "memory");
+}
 template <typename T, int D, bool VEC>
 struct TileLoader {
     static constexpr int NS = NSplit<T>::value;
     static constexpr int CPR = D / 8;                  // 16-byte chunks per row
     static constexpr int CHUNKS = kKT * CPR;           // per tile image
     static constexpr int CPT = CHUNKS / 256;           // chunks per thread
-    Chunk8<T> reg[CPT];
+    static constexpr bool DMA = HVC_ATTN_DMA && VEC && sizeof(T) == 2;
+    Chunk8<T> reg[DMA ? 1 : CPT];
     const T* next;                                     // this thread's first chunk in the next tile (VEC path)
     int64_t step, rstep;                               // elements between consecutive tiles / between a thread's chunks
+    int drow, dch;                                     // DMA: tile row / logical chunk of this lane's first piece
+    int dwave;                                         // DMA: element offset of this wavefront's share of a piece inside the image
 
     // row0 = first row of the first tile this loader will be asked for; tiles are then requested in order.
     __device__ __forceinline__ void init(const T* base, int64_t sn, int row0, int tid) {
         step = (int64_t)kKT * sn;
         rstep = (int64_t)(256 / CPR) * sn;             // chunk c of a thread sits 256 / CPR rows below chunk c - 1
-        next = base + (int64_t)(row0 + tid / CPR) * sn + (tid % CPR) * 8;
+        if constexpr (DMA) {
+            drow = tid / CPR;                          // physical chunk tid (+ 256 per piece) = row tid / CPR, slot tid % CPR
+            dch = (tile_off<D>(drow, tid % CPR) - drow * D) >> 3;      // the logical chunk stored in that slot (XOR: involution);
+            dwave = __builtin_amdgcn_readfirstlane((tid >> 6) * 64 * 8);   // rows 256 / CPR further down swizzle the same way
+            next = base + (int64_t)(row0 + drow) * sn + dch * 8;
+        } else {
+            next = base + (int64_t)(row0 + tid / CPR) * sn + (tid % CPR) * 8;
+        }
     }
     // Full tiles take the incremental addresses (one 64-bit add per chunk, no bounds selects); a ragged or
-    // unaligned tile goes through the clamped / per-element path.
-    __device__ __forceinline__ void issue(const T* base, int64_t sn, int row0, int nrows, int tid) {
-        if (VEC && row0 + kKT <= nrows) {
+    // unaligned tile goes through the clamped / per-element path.  dst: the image(s) of the tile being requested (DMA form).
+    __device__ __forceinline__ void issue(const T* base, int64_t sn, int row0, int nrows, int tid, bf16* dst) {
+        if constexpr (DMA) {
+            const bool full = row0 + kKT <= nrows;
+#pragma unroll
+            for (int i = 0; i < CPT; ++i) {
+                const T* src = full ? next + i * rstep
+                                    : base + (int64_t)min(row0 + drow + i * (256 / CPR), nrows - 1) * sn + dch * 8;
+                lds_dma16(src, dst + (i * 256 * 8 + dwave));
+            }
+        } else if (VEC && row0 + kKT <= nrows) {
 #pragma unroll
             for (int i = 0; i < CPT; ++i) reg[i] = load_chunk<T>(next + i * rstep, 8, true);
         } else {
@@ -94,15 +138,21 @@ struct TileLoader {
     }
     // images: NS consecutive tiles of kKT*D bf16
     __device__ __forceinline__ void commit(bf16* images, int tid) {
+        if constexpr (!DMA) {
 #pragma unroll
-        for (int i = 0; i < CPT; ++i) {
-            int c = tid + 256 * i;
-            int row = c / CPR, ch = c % CPR;
-            bf16x8 im[NS];
-            chunk_split<T>(reg[i], im);
+            for (int i = 0; i < CPT; ++i) {
+                int c = tid + 256 * i;
+                int row = c / CPR, ch = c % CPR;
+                bf16x8 im[NS];
+                chunk_split<T>(reg[i], im);
 #pragma unroll
-            for (int s = 0; s < NS; ++s) tile_store<D>(images + s * (kKT * D), row, ch, im[s]);
+                for (int s = 0; s < NS; ++s) tile_store<D>(images + s * (kKT * D), row, ch, im[s]);
+            }
         }
+    }
+    // every DMA this wavefront issued has landed (call before the barrier that publishes the tile)
+    static __device__ __forceinline__ void wait() {
+        if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
 };
 
@@ -190,10 +240,11 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 3 : 2) void attn_fwd_kernel(c
     const int nt = (a.Nk + kKT - 1) / kKT;
     kl.init(kp, a.k_sn, 0, tid);
     vl.init(vp, a.v_sn, 0, tid);
-    kl.issue(kp, a.k_sn, 0, a.Nk, tid);
-    vl.issue(vp, a.v_sn, 0, a.Nk, tid);
+    kl.issue(kp, a.k_sn, 0, a.Nk, tid, Kt(0));
+    vl.issue(vp, a.v_sn, 0, a.Nk, tid, Vt(0));
     kl.commit(Kt(0), tid);
     vl.commit(Vt(0), tid);
+    kl.wait();
     __syncthreads();
 
     // Reference exponent msc (exp2 units) of this lane's query row; p = exp2(s - msc) <= 2^kRescaleLog2.  -msc is
@@ -234,8 +285,8 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 3 : 2) void attn_fwd_kernel(c
         constexpr int buf = decltype(buf_tag)::value;
         constexpr int KOFF = (buf * 2 + 0) * NS * TILE, VOFF = (buf * 2 + 1) * NS * TILE;
         if (t + 1 < nt) {
-            kl.issue(kp, a.k_sn, (t + 1) * kKT, a.Nk, tid);
-            vl.issue(vp, a.v_sn, (t + 1) * kKT, a.Nk, tid);
+            kl.issue(kp, a.k_sn, (t + 1) * kKT, a.Nk, tid, Kt(buf ^ 1));
+            vl.issue(vp, a.v_sn, (t + 1) * kKT, a.Nk, tid, Vt(buf ^ 1));
         }
         // S^T[key][q] - msc[q] = K (c Q)^T + (-msc)
         f32x16 st[2];
@@ -340,6 +391,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 3 : 2) void attn_fwd_kernel(c
             kl.commit(Kt(buf ^ 1), tid);
             vl.commit(Vt(buf ^ 1), tid);
         }
+        kl.wait();
         __syncthreads();
     };
     const bool ragged = (a.Nk % kKT) != 0;
@@ -738,10 +790,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a_in
     const int nt = (a.Nk + kKT - 1) / kKT;
     kl.init(kp, a.k_sn, 0, tid);
     vl.init(vp, a.v_sn, 0, tid);
-    kl.issue(kp, a.k_sn, 0, a.Nk, tid);
-    vl.issue(vp, a.v_sn, 0, a.Nk, tid);
+    kl.issue(kp, a.k_sn, 0, a.Nk, tid, Kt(0));
+    vl.issue(vp, a.v_sn, 0, a.Nk, tid, Vt(0));
     kl.commit(Kt(0), tid);
     vl.commit(Vt(0), tid);
+    kl.wait();
     __syncthreads();
 
     f32x16 dq[D / 32];
@@ -770,8 +823,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a_in
         constexpr int buf = decltype(buf_tag)::value;
         constexpr int KOFF = (buf * 2 + 0) * NS * TILE, VOFF = (buf * 2 + 1) * NS * TILE;
         if (t + 1 < nt) {
-            kl.issue(kp, a.k_sn, (t + 1) * kKT, a.Nk, tid);
-            vl.issue(vp, a.v_sn, (t + 1) * kKT, a.Nk, tid);
+            kl.issue(kp, a.k_sn, (t + 1) * kKT, a.Nk, tid, Kt(buf ^ 1));
+            vl.issue(vp, a.v_sn, (t + 1) * kKT, a.Nk, tid, Vt(buf ^ 1));
         }
         f32x16 st[2], dpt[2];
 #pragma unroll
@@ -846,6 +899,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a_in
             kl.commit(Kt(buf ^ 1), tid);
             vl.commit(Vt(buf ^ 1), tid);
         }
+        kl.wait();
         __syncthreads();
     };
     const bool ragged = (a.Nk % kKT) != 0;
@@ -924,18 +978,23 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a_i
     const int t_begin = split * per_split;
     const int nt = min(nt_all, t_begin + per_split);      // this workgroup sweeps query tiles [t_begin, nt)
     float st_l = 0.f, st_d = 0.f;
+    // The row constants are only LOADED at the start of a tile; the arithmetic on them waits until commit time at its end.  (Scaling
+    // them right away put an s_waitcnt vmcnt(0) behind the loads - in wavefront 0 only - i.e. the full latency of every load just
+    // requested, tile loads included, at the head of each tile, and the other three wavefronts then waited for it at the barrier.)
+    bool st_ok = false;
     auto issue_stat = [&](int t) {
         if (tid < kKT) {
-            int q = t * kKT + tid;
-            const bool ok = q < a.Nq;
-            st_l = ok ? -a.lse[(int64_t)bh * a.Nq + q] * kLog2e : -INFINITY;      // out-of-range query rows: p = exp2(-inf) = 0
-            st_d = ok ? -a.delta[(int64_t)bh * a.Nq + q] * (DROP ? 1.f / a.keep_scale : 1.f) : 0.f;
+            const int q = t * kKT + tid;
+            st_ok = q < a.Nq;
+            const int qc = st_ok ? q : a.Nq - 1;
+            st_l = a.lse[(int64_t)bh * a.Nq + qc];
+            st_d = a.delta[(int64_t)bh * a.Nq + qc];
         }
     };
     auto commit_stat = [&](int buf) {
         if (tid < kKT) {
-            stat[(buf * 2 + 0) * kKT + tid] = st_l;
-            stat[(buf * 2 + 1) * kKT + tid] = st_d;
+            stat[(buf * 2 + 0) * kKT + tid] = st_ok ? -st_l * kLog2e : -INFINITY;      // out-of-range query rows: p = exp2(-inf) = 0
+            stat[(buf * 2 + 1) * kKT + tid] = st_ok ? -st_d * (DROP ? 1.f / a.keep_scale : 1.f) : 0.f;
         }
     };
     // thread -> (q row tid>>2 of the tile, 32-key quarter tid&3 of the workgroup's 128 keys): 8 hashes, 32 lots
@@ -956,13 +1015,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a_i
     };
     ql.init(qp, a.q_sn, t_begin * kKT, tid);
     dl.init(dop, a.do_sn, t_begin * kKT, tid);
-    ql.issue(qp, a.q_sn, t_begin * kKT, a.Nq, tid);
-    dl.issue(dop, a.do_sn, t_begin * kKT, a.Nq, tid);
+    ql.issue(qp, a.q_sn, t_begin * kKT, a.Nq, tid, Qt(t_begin & 1));
+    dl.issue(dop, a.do_sn, t_begin * kKT, a.Nq, tid, Dt(t_begin & 1));
     issue_stat(t_begin);
     ql.commit(Qt(t_begin & 1), tid);
     dl.commit(Dt(t_begin & 1), tid);
     commit_stat(t_begin & 1);
     gen_lots(t_begin, t_begin & 1);
+    ql.wait();
     __syncthreads();
 
     const int ts = drop_ts(a);
@@ -992,8 +1052,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a_i
         constexpr int buf = decltype(buf_tag)::value;
         constexpr int QOFF = (buf * 2 + 0) * NS * TILE, DOFF = (buf * 2 + 1) * NS * TILE;
         if (t + 1 < nt) {
-            ql.issue(qp, a.q_sn, (t + 1) * kKT, a.Nq, tid);
-            dl.issue(dop, a.do_sn, (t + 1) * kKT, a.Nq, tid);
+            ql.issue(qp, a.q_sn, (t + 1) * kKT, a.Nq, tid, Qt(buf ^ 1));
+            dl.issue(dop, a.do_sn, (t + 1) * kKT, a.Nq, tid, Dt(buf ^ 1));
             issue_stat(t + 1);
         }
 #pragma unroll
@@ -1086,6 +1146,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a_i
             dl.commit(Dt(buf ^ 1), tid);
             commit_stat(buf ^ 1);
         }
+        ql.wait();
         __syncthreads();
     };
     {

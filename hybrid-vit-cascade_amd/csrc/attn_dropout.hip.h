@@ -53,13 +53,14 @@ __device__ __forceinline__ void drop_keep4(uint32_t mixed, int ts, bool (&keep)[
 }
 // out[e] = keep(e) ? x[e] : alt for the four consecutive keys of one group.  The low lots are tested by a true 16-bit compare
 // (v_cmp_ge_i16 reads bits 15:0 of both operands); written as `(int16_t)w >= (int16_t)ts` hipcc canonicalises the test into
-// a shift and a 32-bit compare, one more instruction per element pair.
+// a shift and a 32-bit compare, one more instruction per element pair.  Only the COMPARE is an asm statement (its operands are
+// the lot word and the threshold); the select is the compiler's own v_cndmask on the lane mask (inverse ballot), because x is
+// a fresh MFMA result in the dQ kernel and hipcc does not pad the MFMA -> VALU read hazard for operands of an asm statement:
+// with the select in asm the dQ kernel read stale accumulators on some shapes (round 3: scripts/attn_determinism.py).
 __device__ __forceinline__ float drop_select_lo(uint32_t w, int ts, float x, float alt) {
     uint64_t m;
-    float r;
     asm("v_cmp_ge_i16_e64 %0, %1, %2" : "=s"(m) : "v"(w), "v"(ts));
-    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(alt), "v"(x), "s"(m));
-    return r;
+    return __builtin_amdgcn_inverse_ballot_w64(m) ? x : alt;
 }
 __device__ __forceinline__ void drop_select4(uint32_t mixed, int ts, const float (&x)[4], float alt, float (&out)[4]) {
     uint32_t a, b;
