@@ -20,6 +20,11 @@
 #include <stdlib.h>
 #include <type_traits>
 
+// Timing-only knock-outs for scripts/gemm_ko.py (wrong results by design; 0 in every shipped build)
+#ifndef HVC_GEMM_KO
+#define HVC_GEMM_KO 0
+#endif
+
 namespace hvc {
 namespace {
 
@@ -123,12 +128,15 @@ struct OperandTile {
     // interior tile, decided once per workgroup: no condition at all around the loads (see the k loop)
     template <int SET>
     __device__ __forceinline__ void issue_fast() {
+#if HVC_GEMM_KO != 2
 #pragma unroll
         for (int c = 0; c < CPT; ++c) reg[SET][c] = load_chunk<T>(next + c * rstep, 8, true);
+#endif
         next += kstep;
     }
     template <int SET>
     __device__ __forceinline__ void commit(bf16* images, int tid) {
+        if (HVC_GEMM_KO == 4) return;
 #pragma unroll
         for (int c = 0; c < CPT; ++c) {
             int id = tid + 256 * c;
@@ -306,8 +314,14 @@ struct GatherTile : OperandTile<T, BK, KM, EXT> {
     }
 };
 
-template <typename TI, typename TO, bool AKM, bool BKM, int GATHER, typename Cfg>
+// FEAT >= 0 (persistent form only): the epilogue options are compile-time constants (kF* bits) instead of GemmArgs fields - the
+// block's four fused projections get a straight-line epilogue (see `if constexpr (FEAT >= 0)` below).
+constexpr int kFGelu = 1, kFGeluGrad = 2, kFZsave = 4, kFGate = 8, kFResidual = 16, kFDrop = 32;
+
+template <typename TI, typename TO, bool AKM, bool BKM, int GATHER, typename Cfg, bool PERSIST = false, int FEAT = -1>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
+    static_assert(!PERSIST || GATHER == 0, "persistent form: both operands in memory");
+    static_assert(FEAT < 0 || PERSIST, "static epilogues exist in the persistent form only");
     constexpr int NS = NSplit<TI>::value;
     constexpr int BK = sizeof(TI) == 2 ? 64 : 32;
     constexpr int kBM = Cfg::BM, kBN = Cfg::BN, MI = Cfg::MI, NI = Cfg::NI;
@@ -334,18 +348,27 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
     // small operand (weights) stays L2-resident anyway.
     const int tiles_m = (g.M + kBM - 1) / kBM, tiles_n = (g.N + kBN - 1) / kBN;
     const int nwg = tiles_m * tiles_n;
-    int w = blockIdx.x;
+    // this workgroup's XCD chunk [c0, c0 + clen) of the work list and its position(s) in it: one position per workgroup
+    // (grid = work list), or - persistent form - positions slot, slot + gridDim.x / 8, ... of a 512-workgroup grid
+    int c0, clen;
     {
         const int total = nwg * g.splitk;
-        const int q = total >> 3, rem = total & 7, xcd = w & 7, slot = w >> 3;
-        w = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + slot;
+        const int q = total >> 3, rem = total & 7, xcd = blockIdx.x & 7;
+        c0 = xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q;
+        clen = q + (xcd < rem ? 1 : 0);
     }
-    const int split = w / nwg;               // split-K slice (0 when splitk == 1)
-    const int id = w % nwg;
-    int tm, tn;
-    if (tiles_m >= tiles_n) { tn = id % tiles_n; tm = id / tiles_n; }
-    else { tm = id % tiles_m; tn = id / tiles_m; }
-    const int i0 = tm * kBM, j0 = tn * kBN;
+    int slot = blockIdx.x >> 3;
+    int split, i0, j0;                       // split-K slice (0 when splitk == 1) and tile origin of the current work item
+    auto decode = [&](int w, int& sp, int& ti0, int& tj0) {
+        sp = w / nwg;
+        const int id = w % nwg;
+        int tm, tn;
+        if (tiles_m >= tiles_n) { tn = id % tiles_n; tm = id / tiles_n; }
+        else { tm = id % tiles_m; tn = id / tiles_m; }
+        ti0 = tm * kBM;
+        tj0 = tn * kBN;
+    };
+    decode(c0 + slot, split, i0, j0);
 
     const TI* Ap = reinterpret_cast<const TI*>(g.A);
     const TI* Bp = reinterpret_cast<const TI*>(g.B);
@@ -363,42 +386,47 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
     // to count the loads in flight at the join, and it then waits for ALL of them (vmcnt(0)) before the LDS commit, i.e. also
     // for the tile requested in this very step; the two-deep prefetch degrades to one.  So the decision is taken once, outside
     // the k loop, and the bulk of the loop (every step that both requests and commits a tile) has no branch in it either.
+    int li0 = i0, lj0 = j0;                  // origin of the tile whose k-tiles are being requested (the NEXT tile while a persistent
+                                             // workgroup finishes the current one)
     auto issue_a = [&](auto set_tag, auto fast_tag, int kt) {
         constexpr int set = decltype(set_tag)::value;
         if constexpr (GA) ta.template issue<set>(g.cg, (int64_t)kt * BK, tid);
         else if constexpr (decltype(fast_tag)::value) ta.template issue_fast<set>();
-        else ta.template issue<set>(Ap, g.lda, i0, g.M, kt * BK, g.K, g.vec_a != 0, tid);
+        else ta.template issue<set>(Ap, g.lda, li0, g.M, kt * BK, g.K, g.vec_a != 0, tid);
     };
     auto issue_b = [&](auto set_tag, auto fast_tag, int kt) {
         constexpr int set = decltype(set_tag)::value;
         if constexpr (GB) tb.template issue<set>(g.cg, (int64_t)kt * BK, tid);
         else if constexpr (decltype(fast_tag)::value) tb.template issue_fast<set>();
-        else tb.template issue<set>(Bp, g.ldb, j0, g.N, kt * BK, g.K, g.vec_b != 0, tid);
+        else tb.template issue<set>(Bp, g.ldb, lj0, g.N, kt * BK, g.K, g.vec_b != 0, tid);
     };
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, 1>;
-    const bool k_full = (int64_t)kt_end * BK <= g.K;
-    const bool all_fast = kt_begin < kt_end && k_full && (GA || (TA::FULL && g.vec_a != 0 && i0 + kBM <= g.M)) && (GB || (TB::FULL && g.vec_b != 0 && j0 + kBN <= g.N));
-
     f32x16 acc[MI][NI];
+    // first two k-tiles of the tile at (ti0, tj0) into the two register sets
+    auto prologue = [&](auto fast_tag, int ti0, int tj0) {
+        li0 = ti0;
+        lj0 = tj0;
+        if constexpr (GA) ta.init(g.cg, ti0, tid);
+        else ta.init(Ap, g.lda, ti0, kt_begin * BK, tid);
+        if constexpr (GB) tb.init(g.cg, tj0, tid);
+        else tb.init(Bp, g.ldb, tj0, kt_begin * BK, tid);
+        issue_a(S0{}, fast_tag, kt_begin);
+        issue_b(S0{}, fast_tag, kt_begin);
+    };
+    auto prologue2 = [&](auto fast_tag) {   // second k-tile (the persistent form requests it after the previous tile's epilogue)
+        if (kt_begin + 1 < kt_end) {
+            issue_a(S1{}, fast_tag, kt_begin + 1);
+            issue_b(S1{}, fast_tag, kt_begin + 1);
+        }
+    };
+    auto mainloop = [&](auto fast_tag) {
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[mi][ni][i] = 0.f;
-
-    auto run = [&](auto fast_tag) {
-    if constexpr (GA) ta.init(g.cg, i0, tid);
-    else ta.init(Ap, g.lda, i0, kt_begin * BK, tid);
-    if constexpr (GB) tb.init(g.cg, j0, tid);
-    else tb.init(Bp, g.ldb, j0, kt_begin * BK, tid);
-    issue_a(S0{}, fast_tag, kt_begin);
-    issue_b(S0{}, fast_tag, kt_begin);
-    if (kt_begin + 1 < kt_end) {
-        issue_a(S1{}, fast_tag, kt_begin + 1);
-        issue_b(S1{}, fast_tag, kt_begin + 1);
-    }
     ta.template commit<0>(At(0), tid);
     tb.template commit<0>(Bt(0), tid);
     __syncthreads();
@@ -418,9 +446,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
 #pragma unroll
-                for (int mi = 0; mi < MI; ++mi) af[s][mi] = TA::frag(At(buf) + s * TA::IMG, 32 * (MI * wm + mi), ks, lane);
+                for (int mi = 0; mi < MI; ++mi) af[s][mi] = HVC_GEMM_KO == 5 ? bf16x8{} + (bf16)(float)(kt + mi) : TA::frag(At(buf) + s * TA::IMG, 32 * (MI * wm + mi), ks, lane);
 #pragma unroll
-                for (int ni = 0; ni < NI; ++ni) bfr[s][ni] = TB::frag(Bt(buf) + s * TB::IMG, 32 * (NI * wn + ni), ks, lane);
+                for (int ni = 0; ni < NI; ++ni) bfr[s][ni] = HVC_GEMM_KO == 5 ? bf16x8{} + (bf16)(float)(kt + ni) : TB::frag(Bt(buf) + s * TB::IMG, 32 * (NI * wn + ni), ks, lane);
             }
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
@@ -430,7 +458,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
                     for (int sa = 0; sa < NS; ++sa)
 #pragma unroll
                         for (int sb = 0; sb < NS; ++sb)
-                            if (sa + sb <= 1) acc[mi][ni] = mfma32(af[sa][mi], bfr[sb][ni], acc[mi][ni]);
+                            if (sa + sb <= 1) {
+                                if (HVC_GEMM_KO == 3) acc[mi][ni][0] += (float)af[sa][mi][0] * (float)bfr[sb][ni][0];
+                                else acc[mi][ni] = mfma32(af[sa][mi], bfr[sb][ni], acc[mi][ni]);
+                            }
         }
         if (BULK || kt + 1 < kt_end) {
             ta.template commit<buf ^ 1>(At(buf ^ 1), tid);
@@ -451,9 +482,19 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
         if (kt < kt_end) kstep(S0{}, std::false_type{}, kt);
     }
     };
-    if (all_fast) run(std::true_type{});
-    else run(std::false_type{});
-
+    auto epilogue = [&](int split, int i0, int j0, auto between) {
+    if (HVC_GEMM_KO == 1) {
+        float sum = 0.f;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int x = 0; x < 16; ++x) sum += acc[mi][ni][x];
+        if (sum == 1.2345e-30f) reinterpret_cast<float*>(g.C)[tid] = sum;
+        between();
+        return;
+    }
     // ---- epilogue: stage the 128 x 128 fp32 tile through LDS (the operand buffers are free now) so that
     // every global access of the epilogue is a 16/32-byte row segment instead of a 2/4-byte column element.
     float* stage = reinterpret_cast<float*>(smem);          // [BM][BN] fp32 (128 x 128: 64 KiB = the operand double buffer)
@@ -471,11 +512,14 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
     const int ch = tid % CHN;                // 8-column chunk of the tile row handled by this thread
     const int trow = tid / CHN;
     const int j = j0 + ch * 8;
-    if (j >= g.N) return;
-    const int nj = min(8, g.N - j);
-    const bool vec = g.vec_epi != 0 && nj == 8;
+    // (persistent form: interior tiles with 16-byte addressable epilogue operands only - none of the element-wise paths is compiled)
+    const bool active = PERSIST || j < g.N;  // (threads past the last column still take part in `between`)
+    const int nj = PERSIST ? 8 : active ? min(8, g.N - j) : 0;
+    const bool vec = PERSIST || (g.vec_epi != 0 && nj == 8);
 
     if (g.splitk > 1) {   // raw fp32 partial tile -> slab `split` of the workspace; reduced by splitk_reduce_kernel
+        between();
+        if (!active) return;
         float* ws = g.workspace + (size_t)split * g.M * g.N;
         for (int row = trow; row < kBM; row += RS) {
             const int i = i0 + row;
@@ -493,35 +537,159 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
     }
 
     TO* Cp = reinterpret_cast<TO*>(g.C);
+    if (g.epi_simple) {
+        // C = alpha A B^T (+ bias): the projections' input gradients and the biased forward projections.  Straight-line: every
+        // staged row of the thread is read first, then converted and stored - no branch and no wait between the stores (the generic
+        // path below tests seven epilogue options per row, and hipcc cannot keep loads or stores in flight across their joins).
+        constexpr int RPTS = kBM / RS;
+        f32x4 a0[RPTS], a1[RPTS];
+#pragma unroll
+        for (int it = 0; it < RPTS; ++it) {
+            const float* sp = stage + (trow + RS * it) * kBN + ch * 8;
+            a0[it] = *reinterpret_cast<const f32x4*>(sp);
+            a1[it] = *reinterpret_cast<const f32x4*>(sp + 4);
+        }
+        float bs[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bs[e] = 0.f;
+        if (g.bias && active) {
+            if (vec && (reinterpret_cast<uintptr_t>(g.bias) & 15) == 0) {
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(g.bias + j), b1 = *reinterpret_cast<const f32x4*>(g.bias + j + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { bs[e] = b0[e]; bs[4 + e] = b1[e]; }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) if (e < nj) bs[e] = g.bias[j + e];
+            }
+        }
+        between();
+        if (!active) return;
+#pragma unroll
+        for (int it = 0; it < RPTS; ++it) {
+            const int i = i0 + trow + RS * it;
+            if (!PERSIST && i >= g.M) break;
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] = a0[it][e] * g.alpha + bs[e]; v[4 + e] = a1[it][e] * g.alpha + bs[4 + e]; }
+            store_n<TO>(Cp + (int64_t)i * g.ldc + j, v, nj, vec);
+        }
+        return;
+    }
     TO* auxp = reinterpret_cast<TO*>(g.aux);
     TI* zp = reinterpret_cast<TI*>(g.zsave);
+    if constexpr (FEAT >= 0) {
+        // Static form of the generic path below for interior, vector-addressable tiles whose 128 rows lie in one batch element:
+        // every global read (bias, gate, residual rows / saved pre-activations) is issued first, then the next tile's operands,
+        // then each row is read from the staged tile, finished and stored - no branch, counted waits only.
+        constexpr bool F_GELU = (FEAT & kFGelu) != 0, F_GGRAD = (FEAT & kFGeluGrad) != 0, F_Z = (FEAT & kFZsave) != 0,
+                       F_GATE = (FEAT & kFGate) != 0, F_RES = (FEAT & kFResidual) != 0, F_DROP = (FEAT & kFDrop) != 0;
+        constexpr int R = kBM / RS;
+        f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0, g0 = b0, g1 = b0;
+        if (g.bias) {
+            b0 = *reinterpret_cast<const f32x4*>(g.bias + j);
+            b1 = *reinterpret_cast<const f32x4*>(g.bias + j + 4);
+        }
+        if constexpr (F_GATE) {
+            const float* gp = g.gate + (int64_t)(i0 / g.rows_per_batch) * g.N + j;
+            g0 = *reinterpret_cast<const f32x4*>(gp);
+            g1 = *reinterpret_cast<const f32x4*>(gp + 4);
+        }
+        f32x4 r0[F_RES ? R : 1], r1[F_RES ? R : 1];
+        Chunk8<TO> pre[F_GGRAD ? R : 1];
+#pragma unroll
+        for (int it = 0; it < R; ++it) {
+            const int i = i0 + trow + RS * it;
+            if constexpr (F_RES) {
+                const float* rp = g.residual + (int64_t)(g.residual_rows > 0 ? i % g.residual_rows : i) * g.ldr + j;
+                r0[it] = *reinterpret_cast<const f32x4*>(rp);
+                r1[it] = *reinterpret_cast<const f32x4*>(rp + 4);
+            }
+            if constexpr (F_GGRAD) pre[it] = load_chunk<TO>(auxp + (int64_t)i * g.ldc + j, 8, true);
+        }
+        between();
+        const uint32_t seed = F_DROP ? seed_with_counter(g.seed_lo, g.seed_ctr) : 0u;
+#pragma unroll
+        for (int it = 0; it < R; ++it) {
+            const int row = trow + RS * it;
+            const int i = i0 + row;
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(stage + row * kBN + ch * 8);
+            const f32x4 a1 = *reinterpret_cast<const f32x4*>(stage + row * kBN + ch * 8 + 4);
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] = a0[e] * g.alpha + b0[e]; v[4 + e] = a1[e] * g.alpha + b1[e]; }
+            const int64_t co = (int64_t)i * g.ldc + j;
+            if constexpr (F_GELU) {
+                store_n<TO>(auxp + co, v, 8, true);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+            }
+            if constexpr (F_GGRAD) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] *= gelu_grad_f(chunk_get<TO>(pre[it], e));
+            }
+            if constexpr (F_DROP) {
+                bool keep[8];
+                drop2d_keep8(drop2d_rowkey(seed, g.seed_hi, (uint64_t)i), (uint32_t)j, g.drop_thresh, keep);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = keep[e] ? v[e] * g.keep_scale : 0.f;
+            }
+            if constexpr (F_Z) store_n<TI>(zp + (int64_t)i * g.ldz + j, v, 8, true);
+            if constexpr (F_GATE) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[e] *= g0[e]; v[4 + e] *= g1[e]; }
+            }
+            if constexpr (F_RES) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[e] += r0[it][e]; v[4 + e] += r1[it][e]; }
+            }
+            store_n<TO>(Cp + co, v, 8, true);
+        }
+        return;
+    }
     float bj[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) bj[e] = (g.bias && e < nj) ? g.bias[j + e] : 0.f;
+    for (int e = 0; e < 8; ++e) bj[e] = 0.f;
+    if constexpr (PERSIST) {
+        if (g.bias) {
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(g.bias + j), b1 = *reinterpret_cast<const f32x4*>(g.bias + j + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { bj[e] = b0[e]; bj[4 + e] = b1[e]; }
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bj[e] = (g.bias && e < nj) ? g.bias[j + e] : 0.f;
+    }
 
     // Issue every global read of the epilogue (residual rows, saved pre-activations) before touching the staged tile,
     // so the 8 row segments of a thread cost one memory round trip instead of eight dependent ones.
-    constexpr int RPT = kBM / RS;           // rows per thread
+    // (persistent form: in two batches of rows - the next tile's operand registers stay live through this epilogue)
+    constexpr int RPT_ALL = kBM / RS;       // rows per thread
+    constexpr int NBATCH = PERSIST && RPT_ALL >= 8 ? 4 : 1, RPT = RPT_ALL / NBATCH;
+#pragma unroll
+    for (int bt = 0; bt < NBATCH; ++bt) {
+    const int trow_b = trow + RS * RPT * bt;
     float rres[RPT][8], rpre[RPT][8];
     if (g.residual) {
 #pragma unroll
         for (int it = 0; it < RPT; ++it) {
-            const int i = i0 + trow + RS * it;
-            if (i < g.M) load_n<float>(g.residual + (int64_t)(g.residual_rows > 0 ? i % g.residual_rows : i) * g.ldr + j, rres[it], nj, vec);
+            const int i = i0 + trow_b + RS * it;
+            if (PERSIST || i < g.M) load_n<float>(g.residual + (int64_t)(g.residual_rows > 0 ? i % g.residual_rows : i) * g.ldr + j, rres[it], nj, vec);
         }
     }
     if (g.act == kActGeluGrad) {
 #pragma unroll
         for (int it = 0; it < RPT; ++it) {
-            const int i = i0 + trow + RS * it;
-            if (i < g.M) load_n<TO>(auxp + (int64_t)i * g.ldc + j, rpre[it], nj, vec);
+            const int i = i0 + trow_b + RS * it;
+            if (PERSIST || i < g.M) load_n<TO>(auxp + (int64_t)i * g.ldc + j, rpre[it], nj, vec);
         }
     }
+    if (bt == 0) between();                 // (persistent form: the next tile's first k-tiles are requested here, behind this tile's own reads)
+    if (!active) return;
 #pragma unroll
     for (int it = 0; it < RPT; ++it) {
-        const int row = trow + RS * it;
+        const int row = trow_b + RS * it;
         const int i = i0 + row;
-        if (i >= g.M) break;
+        if (!PERSIST && i >= g.M) break;
         float v[8];
         {
             const f32x4 a0 = *reinterpret_cast<const f32x4*>(stage + row * kBN + ch * 8);
@@ -561,6 +729,45 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
             for (int e = 0; e < 8; ++e) v[e] += rres[it][e];
         }
         store_n<TO>(Cp + co, v, nj, vec);
+    }
+    }
+    };
+
+    const bool k_full = (int64_t)kt_end * BK <= g.K;
+    if constexpr (!PERSIST) {
+        const bool all_fast = kt_begin < kt_end && k_full && (GA || (TA::FULL && g.vec_a != 0 && i0 + kBM <= g.M)) && (GB || (TB::FULL && g.vec_b != 0 && j0 + kBN <= g.N));
+        if (all_fast) { prologue(std::true_type{}, i0, j0); prologue2(std::true_type{}); mainloop(std::true_type{}); }
+        else { prologue(std::false_type{}, i0, j0); prologue2(std::false_type{}); mainloop(std::false_type{}); }
+        epilogue(split, i0, j0, [] {});
+        return;
+    }
+    // Persistent form (the launcher guarantees: no split-K, every tile interior, vector-addressable operands): a workgroup walks
+    // positions slot, slot + step, ... of its XCD's chunk and requests the next tile's first two k-tiles from inside the current
+    // tile's epilogue, so that their memory latency - half of a K = 256 tile's life otherwise - runs under the LDS staging and
+    // the output stores.
+    if constexpr (PERSIST) {
+        const int step = gridDim.x >> 3;
+        // Stagger: all 512 workgroups would otherwise walk load -> multiply -> store in step and the memory system would see a read
+        // burst, silence, a write burst.  The second workgroup of every CU (slots 32.. of its XCD: the dispatcher fills the XCD's 32
+        // CUs once before it doubles up) starts late by g.persistent - 1 units of ~0.4 us, so that its stores fall under its
+        // partner's loads; a persistent workgroup keeps that phase for its whole tile list.
+        if (slot >= 32)
+            for (int d = 1; d < g.persistent; ++d) __builtin_amdgcn_s_sleep(16);
+        prologue(std::true_type{}, i0, j0);
+        for (;;) {
+            prologue2(std::true_type{});
+            mainloop(std::true_type{});
+            const int nslot = slot + step;
+            if (nslot >= clen) break;
+            int nsplit, ni0, nj0;
+            decode(c0 + nslot, nsplit, ni0, nj0);
+            epilogue(split, i0, j0, [&] { prologue(std::true_type{}, ni0, nj0); });
+            __syncthreads();                 // the staged tile has been read: the operand buffers may be written again
+            slot = nslot;
+            i0 = ni0;
+            j0 = nj0;
+        }
+        epilogue(split, i0, j0, [] {});
     }
 }
 
@@ -625,6 +832,49 @@ hipError_t launch(const GemmArgs& g_in, hipStream_t st) {
         if (want >= 2) {
             const int per_split = (nkt + want - 1) / want;
             g.splitk = (nkt + per_split - 1) / per_split;      // no empty trailing slice (the kernel derives the same per-slice count)
+        }
+    }
+    g.epi_simple = g.act == kActNone && !g.aux && !g.zsave && !g.gate && !g.residual && !g.drop_thresh && !g.omap;
+    // Persistent form for the token-matrix projections (65536 x {256..1024} x {256..1024}: thousands of tiles of 4 - 16 k-steps):
+    // every tile interior and vector-addressable, at least two tiles per resident workgroup.  HVC_GEMM_PERSISTENT=0 disables (A/B).
+    static const bool persistent_on = [] { const char* e = getenv("HVC_GEMM_PERSISTENT"); return !(e && e[0] == '0'); }();
+    using TA = OperandTile<TI, BK, AKM, kBM>;
+    using TB = OperandTile<TI, BK, BKM, kBN>;
+    static const int stagger = [] { const char* e = getenv("HVC_GEMM_STAGGER"); return e ? atoi(e) : 0; }();
+    g.persistent = (1 + stagger) * (int)(persistent_on && GATHER == 0 && g.splitk == 1 && tiles >= 1024 && TA::FULL && TB::FULL && g.vec_a && g.vec_b && g.vec_epi && !g.omap && (reinterpret_cast<uintptr_t>(g.bias) & 15) == 0 &&
+                   g.M % kBM == 0 && g.N % kBN == 0 && g.K % BK == 0);
+    if constexpr (GATHER == 0) {
+        if (g.persistent) {
+            auto launch_p = [&](auto kp, bool& raised) -> hipError_t {
+                if (lds > 48 * 1024 && !raised) {
+                    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kp), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                    if (e != hipSuccess) return e;
+                    raised = true;
+                }
+                hipLaunchKernelGGL(kp, dim3(512), dim3(256), lds, st, g);
+                return hipGetLastError();
+            };
+            // the block's fused projections (training form: dropout on) on 128 x 128 tiles: static epilogues
+            if constexpr (std::is_same_v<Cfg, Tile128> && std::is_same_v<TI, bf16> && !AKM) {
+                const int feat = (g.act == kActGelu ? kFGelu : 0) | (g.act == kActGeluGrad ? kFGeluGrad : 0) | (g.zsave ? kFZsave : 0) |
+                                 (g.gate ? kFGate : 0) | (g.residual ? kFResidual : 0) | (g.drop_thresh ? kFDrop : 0);
+                const bool aux_ok = g.act == kActNone ? !g.aux : g.aux != nullptr;
+                const bool batch_ok = !g.gate || (g.rows_per_batch > 0 && g.rows_per_batch % kBM == 0 && (reinterpret_cast<uintptr_t>(g.gate) & 15) == 0);
+                if (!g.epi_simple && aux_ok && batch_ok) {
+                    static thread_local bool r1 = false, r2 = false, r3 = false, r4 = false;
+                    if constexpr (!BKM && std::is_same_v<TO, bf16>)
+                        if (feat == (kFGelu | kFDrop)) return launch_p(gemm_kernel<TI, TO, AKM, BKM, GATHER, Cfg, true, kFGelu | kFDrop>, r1);
+                    if constexpr (BKM && std::is_same_v<TO, bf16>)
+                        if (feat == (kFGeluGrad | kFDrop)) return launch_p(gemm_kernel<TI, TO, AKM, BKM, GATHER, Cfg, true, kFGeluGrad | kFDrop>, r2);
+                    if constexpr (!BKM && std::is_same_v<TO, float>) {
+                        if (feat == (kFZsave | kFGate | kFResidual | kFDrop))
+                            return launch_p(gemm_kernel<TI, TO, AKM, BKM, GATHER, Cfg, true, kFZsave | kFGate | kFResidual | kFDrop>, r3);
+                        if (feat == (kFResidual | kFDrop)) return launch_p(gemm_kernel<TI, TO, AKM, BKM, GATHER, Cfg, true, kFResidual | kFDrop>, r4);
+                    }
+                }
+            }
+            static thread_local bool lds_raised_p = false;
+            return launch_p(gemm_kernel<TI, TO, AKM, BKM, GATHER, Cfg, true>, lds_raised_p);
         }
     }
     hipLaunchKernelGGL(k, dim3(tiles * g.splitk), dim3(256), lds, st, g);

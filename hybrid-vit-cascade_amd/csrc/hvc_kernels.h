@@ -93,6 +93,8 @@ struct GemmArgs {
     float* workspace;        // optional split-K scratch (fp32), workspace_floats long
     int64_t workspace_floats;
     int splitk;              // filled in by the launcher
+    int epi_simple;          // filled in by the launcher: C = alpha A B^T (+ bias), none of the other epilogue options
+    int persistent;          // filled in by the launcher: 512 workgroups walk the tile list (see gemm_kernel)
     // optional output row map (one parity class of a strided convolution's input gradient writes its rows into the interleaved
     // positions of dx): row i = ((b * oD + d) * oH + h) * oW + w  ->  element offset o_base + b o_sb + d o_sd + h o_sh + w o_sw
     int omap;
