@@ -446,8 +446,11 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 3 : 2) void attn_fwd_kernel(c
 // (row, key) as everywhere else: a 32-key tile t is half t & 1 of the 64-key hash tile t >> 1.
 constexpr int kQB2 = 256, kKT2 = 32;
 
-template <int D, bool DROP>
-__global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const AttnArgs a_in) {
+// WAVES = 8 (HVC_ATTN_FWD_WAVES=8, d = 64): 512 query rows per workgroup, one workgroup per CU; threads 0-255 load the K chunk of a
+// tile, threads 256-511 its V chunk.
+template <int D, bool DROP, int WAVES = 4>
+__global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void attn_fwd2_kernel(const AttnArgs a_in) {
+    constexpr int QBW = 64 * WAVES, THREADS = 64 * WAVES;
     AttnArgs a = a_in;
     a.seed_lo = seed_with_counter(a_in.seed_lo, a_in.seed_ctr);
     using T = bf16;
@@ -458,7 +461,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const AttnArgs a_in) 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
 
-    const int nqb = (a.Nq + kQB2 - 1) / kQB2;
+    const int nqb = (a.Nq + QBW - 1) / QBW;
     int bh, qb;
     block_map(blockIdx.x, a.B * a.H, nqb, bh, qb);
     const int b = bh / a.H, hh = bh % a.H;
@@ -467,7 +470,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const AttnArgs a_in) 
     const T* vp = reinterpret_cast<const T*>(a.v) + b * a.v_sb + hh * a.v_sh;
     T* op = reinterpret_cast<T*>(a.o) + b * a.o_sb + hh * a.o_sh;
 
-    const int q0 = qb * kQB2 + wave * 64;
+    const int q0 = qb * QBW + wave * 64;
     const float sl2 = a.scale * kLog2e;
     bf16x8 qf[2][1][D / 16];
     uint32_t rowkey[2];
@@ -485,10 +488,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const AttnArgs a_in) 
     // Two register sets: tile t+2 is requested at the start of tile t and tile t+1 (requested a tile earlier) is written to LDS
     // at its end - a load has two tiles to arrive.  FAST (the tile is full): no condition around the loads; the bulk of the
     // sweep uses only that form, so hipcc can count the loads in flight and waits for the older tile alone.
-    constexpr bool HALF = kKT2 * CPR == 128;
-    static_assert(HALF || kKT2 * CPR == 256, "one or two chunks per thread");
-    const int ltid = HALF ? (tid & 127) : tid;
-    const bool isv = HALF && tid >= 128;
+    constexpr int NCH = kKT2 * CPR;                      // chunks per operand tile
+    constexpr bool HALF = 2 * NCH == THREADS;            // first half of the workgroup loads K, second half V
+    static_assert(HALF || NCH == THREADS, "one or two chunks per thread");
+    const int ltid = HALF ? (tid % NCH) : tid;
+    const bool isv = HALF && tid >= NCH;
     const int lrow = ltid / CPR, lch = ltid % CPR;
     const T* xbase = isv ? vp : kp;                      // HALF: this thread's operand
     const int64_t xsn = isv ? a.v_sn : a.k_sn;
@@ -699,7 +703,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const AttnArgs a_in) 
     for (int blk = 0; blk < 2; ++blk) {
         const float ltot = l[blk] + __shfl_xor(l[blk], 32, 64);
         const float inv = (DROP ? a.keep_scale : 1.f) / ltot;
-        const int qrow = qb * kQB2 + (int)(threadIdx.x >> 6) * 64 + 32 * blk + (int)(threadIdx.x & 31);      // recomputed: not kept live through the sweep
+        const int qrow = qb * QBW + (int)(threadIdx.x >> 6) * 64 + 32 * blk + (int)(threadIdx.x & 31);      // recomputed: not kept live through the sweep
         if (qrow < a.Nq) {
             T* orow = op + (int64_t)qrow * a.o_sn;
 #pragma unroll
@@ -746,8 +750,11 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const AttnArgs a) {
 // ---------------------------------------------------------------------------------
 // backward: dQ
 // ---------------------------------------------------------------------------------
-template <typename T, int D, bool DROP, bool VEC>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a_in) {
+// WAVES = 8 (round 3; chosen by launch_bwd): 256 query rows per workgroup, one workgroup per CU; the K / V tiles are staged once for eight
+// wavefronts (by wavefronts 0-3) - see attn_bwd_dkv_kernel.
+template <typename T, int D, bool DROP, bool VEC, int WAVES = 4>
+__global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void attn_bwd_dq_kernel(const AttnArgs a_in) {
+    constexpr int QB = 32 * WAVES;
     AttnArgs a = a_in;
     a.seed_lo = seed_with_counter(a_in.seed_lo, a_in.seed_ctr);
     constexpr int NS = NSplit<T>::value;
@@ -756,8 +763,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a_in
     bf16* lds = reinterpret_cast<bf16*>(smem);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
+    const bool loader = WAVES == 4 || tid < 256;
 
-    const int nqb = (a.Nq + kQB - 1) / kQB;
+    const int nqb = (a.Nq + QB - 1) / QB;
     int bh, qb;
     block_map(blockIdx.x, a.B * a.H, nqb, bh, qb);
     const int b = bh / a.H, hh = bh % a.H;
@@ -767,7 +775,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a_in
     const T* dop = reinterpret_cast<const T*>(a.dout) + b * a.do_sb + hh * a.do_sh;
     T* dqp = reinterpret_cast<T*>(a.dq) + b * a.dq_sb + hh * a.dq_sh;
 
-    const int q0 = qb * kQB + wave * 32;
+    const int q0 = qb * QB + wave * 32;
     const int qrow = q0 + r;
     const bool qvalid = qrow < a.Nq;
     const int qrow_c = qvalid ? qrow : a.Nq - 1;
@@ -788,12 +796,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a_in
     auto Kt = [&](int buf) { return lds + (buf * 2 + 0) * NS * TILE; };
     auto Vt = [&](int buf) { return lds + (buf * 2 + 1) * NS * TILE; };
     const int nt = (a.Nk + kKT - 1) / kKT;
-    kl.init(kp, a.k_sn, 0, tid);
-    vl.init(vp, a.v_sn, 0, tid);
-    kl.issue(kp, a.k_sn, 0, a.Nk, tid, Kt(0));
-    vl.issue(vp, a.v_sn, 0, a.Nk, tid, Vt(0));
-    kl.commit(Kt(0), tid);
-    vl.commit(Vt(0), tid);
+    if (loader) {
+        kl.init(kp, a.k_sn, 0, tid);
+        vl.init(vp, a.v_sn, 0, tid);
+        kl.issue(kp, a.k_sn, 0, a.Nk, tid, Kt(0));
+        vl.issue(vp, a.v_sn, 0, a.Nk, tid, Vt(0));
+        kl.commit(Kt(0), tid);
+        vl.commit(Vt(0), tid);
+    }
     kl.wait();
     __syncthreads();
 
@@ -822,7 +832,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a_in
         constexpr bool MASK = decltype(mask_tag)::value;
         constexpr int buf = decltype(buf_tag)::value;
         constexpr int KOFF = (buf * 2 + 0) * NS * TILE, VOFF = (buf * 2 + 1) * NS * TILE;
-        if (t + 1 < nt) {
+        if (t + 1 < nt && loader) {
             kl.issue(kp, a.k_sn, (t + 1) * kKT, a.Nk, tid, Kt(buf ^ 1));
             vl.issue(vp, a.v_sn, (t + 1) * kKT, a.Nk, tid, Vt(buf ^ 1));
         }
@@ -895,7 +905,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a_in
                 }
             }
         }
-        if (t + 1 < nt) {
+        if (t + 1 < nt && loader) {
             kl.commit(Kt(buf ^ 1), tid);
             vl.commit(Vt(buf ^ 1), tid);
         }
@@ -930,8 +940,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a_in
 // ---------------------------------------------------------------------------------
 // backward: dK, dV
 // ---------------------------------------------------------------------------------
-template <typename T, int D, bool DROP, bool VEC>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a_in) {
+// WAVES = 4: 128 keys per workgroup, two workgroups per CU.  WAVES = 8 (round 3; chosen by launch_bwd): 256 keys per
+// workgroup, one per CU - the Q / dO tiles, row constants and lots are staged once for eight wavefronts instead of four (by
+// wavefronts 0-3, whose loader instructions also set them half a step behind 4-7), one barrier keeps the two wavefronts of a SIMD
+// in a fixed phase.
+template <typename T, int D, bool DROP, bool VEC, int WAVES = 4>
+__global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void attn_bwd_dkv_kernel(const AttnArgs a_in) {
+    constexpr int KB = 32 * WAVES;                  // keys per workgroup
+    constexpr int LS = WAVES * kLotPart;            // lots per tile row
+    static_assert(WAVES == 4 || WAVES == 8, "4 or 8 wavefronts");
     AttnArgs a = a_in;
     a.seed_lo = seed_with_counter(a_in.seed_lo, a_in.seed_ctr);
     constexpr int NS = NSplit<T>::value;
@@ -939,13 +956,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a_i
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16* lds = reinterpret_cast<bf16*>(smem);                       // [buf][Q|dO][NS][TILE]
     float* stat = reinterpret_cast<float*>(lds + 4 * NS * TILE);     // [buf][lse2|delta][kKT]
-    // [buf][64 q][kLotStride] 16-bit dropout lots of the current q-tile x this workgroup's 128 keys, generated cooperatively
+    // [buf][64 q][LS] 16-bit dropout lots of the current q-tile x this workgroup's keys, generated cooperatively
     // (one hash per 4 keys, as in the forward) so that the per-element cost is a 2-byte LDS read + compare + selects.
     uint16_t* lots = reinterpret_cast<uint16_t*>(stat + 2 * 2 * kKT);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool loader = WAVES == 4 || tid < 256;    // the tile loaders are written for 256 threads
     const int r = lane & 31, h = lane >> 5;
 
-    const int nkb = (a.Nk + kQB - 1) / kQB;
+    const int nkb = (a.Nk + KB - 1) / KB;
     const int nwg = nkb * a.B * a.H;
     const int split = blockIdx.x / nwg;          // query-range slice (0 when qsplit == 1)
     int bh, kb;
@@ -958,7 +976,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a_i
     T* dkp = reinterpret_cast<T*>(a.dk) + b * a.dk_sb + hh * a.dk_sh;
     T* dvp = reinterpret_cast<T*>(a.dv) + b * a.dv_sb + hh * a.dv_sh;
 
-    const int k0 = kb * kQB + wave * 32;
+    const int k0 = kb * KB + wave * 32;
     const int krow = k0 + r;
     const bool kvalid = krow < a.Nk;
     const int krow_c = kvalid ? krow : a.Nk - 1;
@@ -997,15 +1015,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a_i
             stat[(buf * 2 + 1) * kKT + tid] = st_ok ? -st_d * (DROP ? 1.f / a.keep_scale : 1.f) : 0.f;
         }
     };
-    // thread -> (q row tid>>2 of the tile, 32-key quarter tid&3 of the workgroup's 128 keys): 8 hashes, 32 lots
+    // thread -> (q row of the tile, 32-key part of the workgroup's keys): 8 hashes, 32 lots
     auto gen_lots = [&](int t, int buf) {
         if constexpr (DROP) {
-            const int ql = tid >> 2, part = tid & 3;
+            const int ql = tid / WAVES, part = tid % WAVES;
             const int q = min(t * kKT + ql, a.Nq - 1);
-            // keys 128 kb + 32 part + 4 u .. + 3: 64-key tile 2 kb + (part >> 1), group j = 8 (part & 1) + u
-            const uint32_t rk0 = drop_rowkey(a, bh, q), tadd = (uint32_t)(2 * kb + (part >> 1)) * kTileAdd;
+            // keys KB kb + 32 part + 4 u .. + 3: 64-key tile (KB / 64) kb + (part >> 1), group j = 8 (part & 1) + u
+            const uint32_t rk0 = drop_rowkey(a, bh, q), tadd = (uint32_t)((KB / 64) * kb + (part >> 1)) * kTileAdd;
             const uint32_t rk[2] = {(rk0 + tadd) ^ drop_grp_a(part & 1), ((rk0 ^ kGrpH) + tadd) ^ drop_grp_a(part & 1)};
-            uint32_t* dst = reinterpret_cast<uint32_t*>(lots + ((size_t)buf * kKT + ql) * kLotStride + kLotPart * part);
+            uint32_t* dst = reinterpret_cast<uint32_t*>(lots + ((size_t)buf * kKT + ql) * LS + kLotPart * part);
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const uint32_t m = rk[u & 1] ^ drop_grp_b(u >> 1);
@@ -1013,13 +1031,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a_i
             }
         }
     };
-    ql.init(qp, a.q_sn, t_begin * kKT, tid);
-    dl.init(dop, a.do_sn, t_begin * kKT, tid);
-    ql.issue(qp, a.q_sn, t_begin * kKT, a.Nq, tid, Qt(t_begin & 1));
-    dl.issue(dop, a.do_sn, t_begin * kKT, a.Nq, tid, Dt(t_begin & 1));
+    if (loader) {
+        ql.init(qp, a.q_sn, t_begin * kKT, tid);
+        dl.init(dop, a.do_sn, t_begin * kKT, tid);
+        ql.issue(qp, a.q_sn, t_begin * kKT, a.Nq, tid, Qt(t_begin & 1));
+        dl.issue(dop, a.do_sn, t_begin * kKT, a.Nq, tid, Dt(t_begin & 1));
+    }
     issue_stat(t_begin);
-    ql.commit(Qt(t_begin & 1), tid);
-    dl.commit(Dt(t_begin & 1), tid);
+    if (loader) {
+        ql.commit(Qt(t_begin & 1), tid);
+        dl.commit(Dt(t_begin & 1), tid);
+    }
     commit_stat(t_begin & 1);
     gen_lots(t_begin, t_begin & 1);
     ql.wait();
@@ -1046,14 +1068,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a_i
         taddr[dt][1] = lds + ob;
     }
     const float* stat_lane = stat + 4 * h;                            // row constants of query rows 4h + {0..3} (+ 8g + 32qt)
-    const uint16_t* lots_lane = lots + 4 * h * kLotStride + wave * kLotPart + r;
+    const uint16_t* lots_lane = lots + 4 * h * LS + wave * kLotPart + r;
 
     auto step = [&](auto buf_tag, int t) {
         constexpr int buf = decltype(buf_tag)::value;
         constexpr int QOFF = (buf * 2 + 0) * NS * TILE, DOFF = (buf * 2 + 1) * NS * TILE;
         if (t + 1 < nt) {
-            ql.issue(qp, a.q_sn, (t + 1) * kKT, a.Nq, tid, Qt(buf ^ 1));
-            dl.issue(dop, a.do_sn, (t + 1) * kKT, a.Nq, tid, Dt(buf ^ 1));
+            if (loader) {
+                ql.issue(qp, a.q_sn, (t + 1) * kKT, a.Nq, tid, Qt(buf ^ 1));
+                dl.issue(dop, a.do_sn, (t + 1) * kKT, a.Nq, tid, Dt(buf ^ 1));
+            }
             issue_stat(t + 1);
         }
 #pragma unroll
@@ -1102,7 +1126,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a_i
                     if constexpr (DROP) {   // 1/(1-p) is folded into delta (pre-divided) and the epilogue scales
 #pragma unroll
                         for (int e = 0; e < 2; ++e) {
-                            const bool keep = (int16_t)lots_lane[(buf * kKT + ro + j + e) * kLotStride] >= (int16_t)ts;
+                            const bool keep = (int16_t)lots_lane[(buf * kKT + ro + j + e) * LS] >= (int16_t)ts;
                             float pdv = keep ? p2[e] : 0.f;
                             asm("" : "+v"(pdv));     // select in fp32, so that the bf16 conversions below stay packed pairs
                             pd2[e] = pdv;
@@ -1142,8 +1166,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a_i
             }
         }
         if (t + 1 < nt) {
-            ql.commit(Qt(buf ^ 1), tid);
-            dl.commit(Dt(buf ^ 1), tid);
+            if (loader) {
+                ql.commit(Qt(buf ^ 1), tid);
+                dl.commit(Dt(buf ^ 1), tid);
+            }
             commit_stat(buf ^ 1);
         }
         ql.wait();
@@ -1212,7 +1238,7 @@ __global__ __launch_bounds__(256) void attn_dkv_reduce_kernel(const AttnArgs a) 
 template <typename T, int D>
 size_t fwd_lds_bytes() { return (size_t)2 * 2 * NSplit<T>::value * kKT * D * sizeof(bf16); }
 template <typename T, int D>
-size_t dkv_lds_bytes(bool drop) { return fwd_lds_bytes<T, D>() + 2 * 2 * kKT * sizeof(float) + (drop ? 2 * kKT * kLotStride * sizeof(uint16_t) : 0); }
+size_t dkv_lds_bytes(bool drop, int waves = 4) { return fwd_lds_bytes<T, D>() + 2 * 2 * kKT * sizeof(float) + (drop ? 2 * kKT * waves * kLotPart * sizeof(uint16_t) : 0); }
 
 // Raises a kernel's dynamic-LDS limit once per (kernel, size): the attribute is sticky, and a driver call per launch would
 // also sit inside hipGraph captures of the training step.
@@ -1247,6 +1273,16 @@ hipError_t launch_fwd(const AttnArgs& a, hipStream_t st) {
         const int force = env ? atoi(env) : 0;
         if (force == 64 || (force != 32 && nqb2 * a.B * a.H >= 512)) {
             const size_t lds2 = (size_t)2 * 2 * kKT2 * D * sizeof(bf16) + extra_lds();
+            static const bool waves8 = [] { const char* e = getenv("HVC_ATTN_FWD_WAVES"); return e && e[0] == '8'; }();
+            if constexpr (D == 64) {
+                if (waves8 && force != 64) {
+                    auto k8 = attn_fwd2_kernel<D, DROP, 8>;
+                    hipError_t e8 = set_lds(k8, lds2);
+                    if (e8 != hipSuccess) return e8;
+                    hipLaunchKernelGGL(k8, dim3(((a.Nq + 511) / 512) * a.B * a.H), dim3(512), lds2, st, a);
+                    return hipGetLastError();
+                }
+            }
             auto k2 = attn_fwd2_kernel<D, DROP>;
             hipError_t e2 = set_lds(k2, lds2);
             if (e2 != hipSuccess) return e2;
@@ -1263,6 +1299,12 @@ hipError_t launch_fwd(const AttnArgs& a, hipStream_t st) {
     return hipGetLastError();
 }
 
+// HVC_ATTN_BWD_WAVES = 4 | 8: pin the workgroup form of the dQ and dK/dV kernels (A/B timing, parity tests of both forms); 0 = by size
+inline int bwd_waves_pin() {
+    const char* e = getenv("HVC_ATTN_BWD_WAVES");
+    return e ? atoi(e) : 0;
+}
+
 template <typename T, int D, bool DROP, bool VEC>
 hipError_t launch_bwd(const AttnArgs& a, hipStream_t st) {
     const int ph = a.phases ? a.phases : 7;
@@ -1273,17 +1315,33 @@ hipError_t launch_bwd(const AttnArgs& a, hipStream_t st) {
         if (e != hipSuccess) return e;
     }
     if (ph & 2) {
-        const int nkb = (a.Nk + kQB - 1) / kQB;
-        const size_t lds = dkv_lds_bytes<T, D>(DROP) + extra_lds();
-        auto k = attn_bwd_dkv_kernel<T, D, DROP, VEC>;
-        hipError_t e = set_lds(k, lds);
-        if (e != hipSuccess) return e;
+        // 256-key workgroups of eight wavefronts once they fill every CU twice over (HVC_ATTN_BWD_WAVES=4 / 8 pins the form)
+        constexpr bool CAN8 = sizeof(T) == 2 && VEC;
+        const int pin = bwd_waves_pin();
+        const bool w8 = CAN8 && pin != 4 && (pin == 8 || (int64_t)((a.Nk + 255) / 256) * a.B * a.H >= 512);
+        const int KBh = w8 ? 256 : kQB;
+        const int nkb = (a.Nk + KBh - 1) / KBh;
+        const size_t lds = dkv_lds_bytes<T, D>(DROP, w8 ? 8 : 4) + extra_lds();
         // Few key blocks (cross-attention, small contexts) leave most CUs idle: slice the query range over more
         // workgroups and sum the fp32 partial dK / dV slabs in a second, deterministic pass.
         AttnArgs b = a;
         b.qsplit = attention_bwd_qsplit(a.B, a.H, a.Nq, a.Nk);
         if (b.qsplit > 1 && (!a.dkv_partial || a.partial_floats < (int64_t)2 * b.qsplit * a.B * a.H * a.Nk * D)) b.qsplit = 1;
-        hipLaunchKernelGGL(k, dim3(nkb * a.B * a.H * b.qsplit), dim3(256), lds, st, b);
+        hipError_t e = hipSuccess;
+        if constexpr (CAN8) {
+            if (w8) {
+                auto k8 = attn_bwd_dkv_kernel<T, D, DROP, VEC, 8>;
+                e = set_lds(k8, lds);
+                if (e != hipSuccess) return e;
+                hipLaunchKernelGGL(k8, dim3(nkb * a.B * a.H * b.qsplit), dim3(512), lds, st, b);
+            }
+        }
+        if (!w8) {
+            auto k = attn_bwd_dkv_kernel<T, D, DROP, VEC>;
+            e = set_lds(k, lds);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(k, dim3(nkb * a.B * a.H * b.qsplit), dim3(256), lds, st, b);
+        }
         e = hipGetLastError();
         if (e != hipSuccess) return e;
         if (b.qsplit > 1) {
@@ -1296,8 +1354,19 @@ hipError_t launch_bwd(const AttnArgs& a, hipStream_t st) {
         }
     }
     if (ph & 4) {
-        const int nqb = (a.Nq + kQB - 1) / kQB;
         const size_t lds = fwd_lds_bytes<T, D>() + extra_lds();
+        if constexpr (sizeof(T) == 2 && VEC) {
+            const int pin = bwd_waves_pin();
+            if (pin != 4 && (pin == 8 || (int64_t)((a.Nq + 255) / 256) * a.B * a.H >= 512)) {
+                const int nqb = (a.Nq + 255) / 256;
+                auto k8 = attn_bwd_dq_kernel<T, D, DROP, VEC, 8>;
+                hipError_t e = set_lds(k8, lds);
+                if (e != hipSuccess) return e;
+                hipLaunchKernelGGL(k8, dim3(nqb * a.B * a.H), dim3(512), lds, st, a);
+                return hipGetLastError();
+            }
+        }
+        const int nqb = (a.Nq + kQB - 1) / kQB;
         auto k = attn_bwd_dq_kernel<T, D, DROP, VEC>;
         hipError_t e = set_lds(k, lds);
         if (e != hipSuccess) return e;

@@ -514,6 +514,29 @@ def test_attention_is_bit_reproducible_with_dropout(shape, dtype):
                 assert torch.equal(a, b), name
 
 
+@pytest.mark.parametrize("shape", [(2, 4, 700, 515, 64, 0.1), (1, 8, 1030, 1100, 32, 0.1), (2, 2, 256, 4096, 64, 0.0), (1, 2, 65, 257, 32, 0.25)])
+def test_attention_backward_eight_wavefront_workgroups_match_four(shape, monkeypatch):
+    """The dQ and dK/dV kernels have a 256-row / 256-key form (eight wavefronts, one workgroup per CU; picked by problem size, here
+    pinned through HVC_ATTN_BWD_WAVES).  A wavefront does the same arithmetic in the same order in both forms, so the gradients
+    must be bit-identical - ragged sizes, both head dims, with and without dropout (the 4-wavefront form is the one the oracle
+    tests cover on small shapes)."""
+    from hvc import ops
+    B, H, Nq, Nk, D, p = shape
+    g = torch.Generator().manual_seed(Nq + Nk)
+    q = torch.randn(B, Nq, H, D, generator=g).to(dev(), torch.bfloat16)
+    k = torch.randn(B, Nk, H, D, generator=g).to(dev(), torch.bfloat16)
+    v = torch.randn(B, Nk, H, D, generator=g).to(dev(), torch.bfloat16)
+    do = torch.randn(B, Nq, H, D, generator=g).to(dev(), torch.bfloat16)
+    o, lse = ops.attention_fwd(q, k, v, D ** -0.5, p, 21)
+    grads = {}
+    for waves in ("4", "8"):
+        monkeypatch.setenv("HVC_ATTN_BWD_WAVES", waves)
+        grads[waves] = ops.attention_bwd(q, k, v, o, do, lse, D ** -0.5, p, 21)
+    for name, a, b in zip(("dq", "dk", "dv"), grads["4"], grads["8"]):
+        assert torch.isfinite(b.float()).all(), name
+        assert torch.equal(a, b), name
+
+
 @pytest.mark.parametrize("p,N", [(0.1, 256), (0.25, 256), (0.1, 1024)])
 def test_attention_dropout_mask_is_bernoulli_like(p, N):
     """Recover the full keep mask of the counter-based dropout (reference: nn.Dropout on the probabilities,
