@@ -841,9 +841,9 @@ hipError_t launch(const GemmArgs& g_in, hipStream_t st) {
     using TA = OperandTile<TI, BK, AKM, kBM>;
     using TB = OperandTile<TI, BK, BKM, kBN>;
     static const int stagger = [] { const char* e = getenv("HVC_GEMM_STAGGER"); return e ? atoi(e) : 0; }();
-    g.persistent = (1 + stagger) * (int)(persistent_on && GATHER == 0 && g.splitk == 1 && tiles >= 1024 && TA::FULL && TB::FULL && g.vec_a && g.vec_b && g.vec_epi && !g.omap && (reinterpret_cast<uintptr_t>(g.bias) & 15) == 0 &&
+    g.persistent = (1 + stagger) * (int)(persistent_on && GATHER == 0 && std::is_same_v<Cfg, Tile128> && g.splitk == 1 && tiles >= 1024 && TA::FULL && TB::FULL && g.vec_a && g.vec_b && g.vec_epi && !g.omap && (reinterpret_cast<uintptr_t>(g.bias) & 15) == 0 &&
                    g.M % kBM == 0 && g.N % kBN == 0 && g.K % BK == 0);
-    if constexpr (GATHER == 0) {
+    if constexpr (GATHER == 0 && std::is_same_v<Cfg, Tile128>) {      // (measured on the 128 x 128 tile only)
         if (g.persistent) {
             auto launch_p = [&](auto kp, bool& raised) -> hipError_t {
                 if (lds > 48 * 1024 && !raised) {
