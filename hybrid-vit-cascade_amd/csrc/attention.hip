@@ -446,7 +446,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 3 : 2) void attn_fwd_kernel(c
 // (row, key) as everywhere else: a 32-key tile t is half t & 1 of the 64-key hash tile t >> 1.
 constexpr int kQB2 = 256, kKT2 = 32;
 
-// WAVES = 8 (HVC_ATTN_FWD_WAVES=8, d = 64): 512 query rows per workgroup, one workgroup per CU; threads 0-255 load the K chunk of a
+// WAVES = 8 (d = 64, chosen by launch_fwd): 512 query rows per workgroup, one workgroup per CU; threads 0-255 load the K chunk of a
 // tile, threads 256-511 its V chunk.
 template <int D, bool DROP, int WAVES = 4>
 __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void attn_fwd2_kernel(const AttnArgs a_in) {
@@ -1273,9 +1273,11 @@ hipError_t launch_fwd(const AttnArgs& a, hipStream_t st) {
         const int force = env ? atoi(env) : 0;
         if (force == 64 || (force != 32 && nqb2 * a.B * a.H >= 512)) {
             const size_t lds2 = (size_t)2 * 2 * kKT2 * D * sizeof(bf16) + extra_lds();
-            static const bool waves8 = [] { const char* e = getenv("HVC_ATTN_FWD_WAVES"); return e && e[0] == '8'; }();
+            // d = 64: 512-row workgroups of eight wavefronts (one per CU) once they fill every CU twice over; HVC_ATTN_FWD_WAVES=4|8 pins the form
             if constexpr (D == 64) {
-                if (waves8 && force != 64) {
+                const char* we = getenv("HVC_ATTN_FWD_WAVES");
+                const int wpin = we ? atoi(we) : 0;
+                if (wpin != 4 && (wpin == 8 || (int64_t)((a.Nq + 511) / 512) * a.B * a.H >= 512)) {
                     auto k8 = attn_fwd2_kernel<D, DROP, 8>;
                     hipError_t e8 = set_lds(k8, lds2);
                     if (e8 != hipSuccess) return e8;

@@ -514,6 +514,27 @@ def test_attention_is_bit_reproducible_with_dropout(shape, dtype):
                 assert torch.equal(a, b), name
 
 
+@pytest.mark.parametrize("shape", [(2, 4, 700, 515, 0.1), (1, 2, 1500, 97, 0.0), (2, 2, 513, 4096, 0.25)])
+def test_attention_forward_eight_wavefront_workgroups_match_four(shape, monkeypatch):
+    """The 64-row forward kernel (d = 64) has a 512-row form (eight wavefronts, one workgroup per CU; picked by problem size, here pinned
+    through HVC_ATTN_FWD_WAVES): same arithmetic per wavefront, so output and log-sum-exp must be bit-identical on ragged shapes,
+    with and without dropout."""
+    from hvc import ops
+    B, H, Nq, Nk, p = shape
+    D = 64
+    g = torch.Generator().manual_seed(Nq * 3 + Nk)
+    q = torch.randn(B, Nq, H, D, generator=g).to(dev(), torch.bfloat16)
+    k = torch.randn(B, Nk, H, D, generator=g).to(dev(), torch.bfloat16)
+    v = torch.randn(B, Nk, H, D, generator=g).to(dev(), torch.bfloat16)
+    monkeypatch.setenv("HVC_ATTN_FWD_ROWS", "64")
+    outs = {}
+    for waves in ("4", "8"):
+        monkeypatch.setenv("HVC_ATTN_FWD_WAVES", waves)
+        outs[waves] = ops.attention_fwd(q, k, v, D ** -0.5, p, 33)
+    assert torch.isfinite(outs["8"][0].float()).all()
+    assert torch.equal(outs["4"][0], outs["8"][0]) and torch.equal(outs["4"][1], outs["8"][1])
+
+
 @pytest.mark.parametrize("shape", [(2, 4, 700, 515, 64, 0.1), (1, 8, 1030, 1100, 32, 0.1), (2, 2, 256, 4096, 64, 0.0), (1, 2, 65, 257, 32, 0.25)])
 def test_attention_backward_eight_wavefront_workgroups_match_four(shape, monkeypatch):
     """The dQ and dK/dV kernels have a 256-row / 256-key form (eight wavefronts, one workgroup per CU; picked by problem size, here
