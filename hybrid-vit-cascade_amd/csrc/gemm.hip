@@ -837,7 +837,7 @@ hipError_t launch(const GemmArgs& g_in, hipStream_t st) {
     g.epi_simple = g.act == kActNone && !g.aux && !g.zsave && !g.gate && !g.residual && !g.drop_thresh && !g.omap;
     // Persistent form for the token-matrix projections (65536 x {256..1024} x {256..1024}: thousands of tiles of 4 - 16 k-steps):
     // every tile interior and vector-addressable, at least two tiles per resident workgroup.  HVC_GEMM_PERSISTENT=0 disables (A/B).
-    static const bool persistent_on = [] { const char* e = getenv("HVC_GEMM_PERSISTENT"); return !(e && e[0] == '0'); }();
+    const bool persistent_on = [] { const char* e = getenv("HVC_GEMM_PERSISTENT"); return !(e && e[0] == '0'); }();      // read per launch: the tests run both forms in one process
     using TA = OperandTile<TI, BK, AKM, kBM>;
     using TB = OperandTile<TI, BK, BKM, kBN>;
     static const int stagger = [] { const char* e = getenv("HVC_GEMM_STAGGER"); return e ? atoi(e) : 0; }();
