@@ -1259,8 +1259,7 @@ hipError_t set_lds(K kernel, size_t bytes) {
 // Experiments only (scripts/attn_ab.py): HVC_ATTN_EXTRA_LDS=<bytes> pads every attention launch's dynamic LDS request, e.g. to
 // force one workgroup per CU and read off how much two co-resident waves per SIMD overlap (profiles/r03_attention_*).
 size_t extra_lds() {
-    static const size_t v = [] { const char* e = getenv("HVC_ATTN_EXTRA_LDS"); return e ? (size_t)atol(e) : (size_t)0; }();
-    return v;
+    return (size_t)option(kOptAttnExtraLds);
 }
 
 template <typename T, int D, bool DROP, bool VEC>
@@ -1269,14 +1268,12 @@ hipError_t launch_fwd(const AttnArgs& a, hipStream_t st) {
         // 64 rows per wavefront once its 256-row workgroups fill every CU twice over; smaller problems keep the 128-row
         // workgroups (more of them, three per CU)
         const int nqb2 = (a.Nq + kQB2 - 1) / kQB2;
-        const char* env = getenv("HVC_ATTN_FWD_ROWS");          // "64" / "32": pin the kernel (parity tests run both on every shape)
-        const int force = env ? atoi(env) : 0;
+        const int force = option(kOptAttnFwdRows);          // 64 / 32: pin the kernel (parity tests run both on every shape)
         if (force == 64 || (force != 32 && nqb2 * a.B * a.H >= 512)) {
             const size_t lds2 = (size_t)2 * 2 * kKT2 * D * sizeof(bf16) + extra_lds();
             // d = 64: 512-row workgroups of eight wavefronts (one per CU) once they fill every CU twice over; HVC_ATTN_FWD_WAVES=4|8 pins the form
             if constexpr (D == 64) {
-                const char* we = getenv("HVC_ATTN_FWD_WAVES");
-                const int wpin = we ? atoi(we) : 0;
+                const int wpin = option(kOptAttnFwdWaves);
                 if (wpin != 4 && (wpin == 8 || (int64_t)((a.Nq + 511) / 512) * a.B * a.H >= 512)) {
                     auto k8 = attn_fwd2_kernel<D, DROP, 8>;
                     hipError_t e8 = set_lds(k8, lds2);
@@ -1303,8 +1300,7 @@ hipError_t launch_fwd(const AttnArgs& a, hipStream_t st) {
 
 // HVC_ATTN_BWD_WAVES = 4 | 8: pin the workgroup form of the dQ and dK/dV kernels (A/B timing, parity tests of both forms); 0 = by size
 inline int bwd_waves_pin() {
-    const char* e = getenv("HVC_ATTN_BWD_WAVES");
-    return e ? atoi(e) : 0;
+    return option(kOptAttnBwdWaves);
 }
 
 template <typename T, int D, bool DROP, bool VEC>

@@ -515,8 +515,7 @@ int64_t attention_fp8_workspace_bytes(int B, int H, int Nk, int D) {
 // HVC_FP8_MX=1 selects the round-3 experiment kernel (32x32x64 products, sum-voted reference); read at every launch so that
 // one process (the parity tests) can run both
 static bool fp8_mx() {
-    const char* e = getenv("HVC_FP8_MX");
-    return e && e[0] == '1';
+    return option(kOptFp8Mx) == 1;
 }
 
 template <int D>

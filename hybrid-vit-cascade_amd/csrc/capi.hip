@@ -20,6 +20,27 @@ std::atomic<const uint32_t*> g_seed_ctr{nullptr};
 
 __global__ void seed_counter_advance_kernel(uint32_t* ctr, uint32_t step) { *ctr += step; }
 
+struct OptionSlot {
+    const char* name;
+    int def_value, min_value;
+};
+const OptionSlot kOptionTable[hvc::kOptCount] = {
+    {"HVC_ATTN_FWD_ROWS", 0, 0},   {"HVC_ATTN_FWD_WAVES", 0, 0},  {"HVC_ATTN_BWD_WAVES", 0, 0},    {"HVC_ATTN_EXTRA_LDS", 0, 0},
+    {"HVC_ATTN_FWD_ASM", 1, 0},    {"HVC_GEMM_PERSISTENT", 1, 0}, {"HVC_GEMM_STAGGER", 0, 0},      {"HVC_GEMM_HALF_TILE", 1, 0},
+    {"HVC_FP8_MX", 0, 0},          {"HVC_CONV_FORCE_ADDR64", 0, 0},
+};
+std::atomic<int> g_options[hvc::kOptCount];
+// environment -> initial values, once, while the library is being loaded (before any launch and before any other thread can call in)
+const bool g_options_ready = [] {
+    for (int i = 0; i < hvc::kOptCount; ++i) {
+        const char* e = getenv(kOptionTable[i].name);
+        int v = e ? atoi(e) : kOptionTable[i].def_value;
+        if (v < kOptionTable[i].min_value) v = kOptionTable[i].min_value;
+        g_options[i].store(v);
+    }
+    return true;
+}();
+
 int fail(int code, const char* msg) {
     snprintf(g_err, sizeof(g_err), "%s", msg);
     return code;
@@ -42,13 +63,52 @@ uint32_t drop_threshold(float p) {
 
 }  // namespace
 
+namespace hvc {
+int option(Option o) { return g_options[o].load(std::memory_order_relaxed); }
+int cu_count() {
+    static const int n = [] {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+        return cus;
+    }();
+    return n;
+}
+}  // namespace hvc
+
 extern "C" {
 
 int hvc_abi_version(void) { return HVC_ABI_VERSION; }
+
+int hvc_set_option(const char* name, int value) {
+    if (!name) return fail(HVC_E_BADARG, "set_option: null name");
+    for (int i = 0; i < hvc::kOptCount; ++i)
+        if (strcmp(name, kOptionTable[i].name) == 0) {
+            if (value < kOptionTable[i].min_value) return fail(HVC_E_BADARG, "set_option: value below the option's minimum");
+            g_options[i].store(value);
+            return 0;
+        }
+    return fail(HVC_E_BADARG, "set_option: unknown option");
+}
+
+int hvc_get_option(const char* name, int* value) {
+    if (!name || !value) return fail(HVC_E_BADARG, "get_option: null argument");
+    for (int i = 0; i < hvc::kOptCount; ++i)
+        if (strcmp(name, kOptionTable[i].name) == 0) {
+            *value = g_options[i].load();
+            return 0;
+        }
+    return fail(HVC_E_BADARG, "get_option: unknown option");
+}
 const char* hvc_last_error(void) { return g_err; }
 
 int hvc_set_seed_counter(const uint32_t* device_counter) {
     g_seed_ctr.store(device_counter);
+    return 0;
+}
+
+int hvc_clear_seed_counter_if(const uint32_t* device_counter) {
+    const uint32_t* expected = device_counter;
+    g_seed_ctr.compare_exchange_strong(expected, nullptr);
     return 0;
 }
 
@@ -362,7 +422,7 @@ int hvc_conv_gemm(int mode, const void* src, const void* other, void* out, int B
     cg.src = src; cg.C = C; cg.SD = SD; cg.SH = SH; cg.SW = SW; cg.KD = KD; cg.KH = KH; cg.KW = KW; cg.stride = stride;
     cg.PD = PD; cg.PH = PH; cg.PW = PW; cg.flip = flip != 0; cg.M = cgeo.M; cg.K = (int)K64;
     const int64_t src_bytes = (int64_t)B * SD * SH * SW * C * (in_dtype == HVC_BF16 ? 2 : 4);
-    static const bool force64 = [] { const char* e = getenv("HVC_CONV_FORCE_ADDR64"); return e && e[0] == '1'; }();   // test hook for the >= 4 GiB path
+    const bool force64 = hvc::option(hvc::kOptConvForceAddr64) == 1;   // test hook for the >= 4 GiB path
     cg.bytes = (src_bytes < (1ll << 32) && !force64) ? (uint32_t)src_bytes : 0u;
     cg.dC = hvc::make_fastdiv((uint32_t)C); cg.dKW = hvc::make_fastdiv((uint32_t)KW); cg.dKH = hvc::make_fastdiv((uint32_t)KH);
     cg.dOW = hvc::make_fastdiv((uint32_t)cgeo.OW); cg.dOH = hvc::make_fastdiv((uint32_t)cgeo.OH); cg.dOD = hvc::make_fastdiv((uint32_t)cgeo.OD);
@@ -445,7 +505,7 @@ int hvc_conv_dx_class(const void* dy, const void* wclass, void* dx, int B, int C
     cg.src = dy; cg.C = Cout; cg.SD = OD; cg.SH = OH; cg.SW = OW; cg.KD = nd; cg.KH = nh; cg.KW = nw; cg.stride = 1;
     cg.PD = -ed; cg.PH = -eh; cg.PW = -ew; cg.flip = 0; cg.M = M; cg.K = (int)K64;
     const int64_t src_bytes = (int64_t)B * OD * OH * OW * Cout * (dtype == HVC_BF16 ? 2 : 4);
-    static const bool force64 = [] { const char* e = getenv("HVC_CONV_FORCE_ADDR64"); return e && e[0] == '1'; }();
+    const bool force64 = hvc::option(hvc::kOptConvForceAddr64) == 1;
     cg.bytes = (src_bytes < (1ll << 32) && !force64) ? (uint32_t)src_bytes : 0u;
     cg.dC = hvc::make_fastdiv((uint32_t)Cout); cg.dKW = hvc::make_fastdiv((uint32_t)nw); cg.dKH = hvc::make_fastdiv((uint32_t)nh);
     cg.dOW = hvc::make_fastdiv((uint32_t)cW); cg.dOH = hvc::make_fastdiv((uint32_t)cH); cg.dOD = hvc::make_fastdiv((uint32_t)cD);

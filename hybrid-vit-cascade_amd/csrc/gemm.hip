@@ -748,10 +748,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
     if constexpr (PERSIST) {
         const int step = gridDim.x >> 3;
         // Stagger: all 512 workgroups would otherwise walk load -> multiply -> store in step and the memory system would see a read
-        // burst, silence, a write burst.  The second workgroup of every CU (slots 32.. of its XCD: the dispatcher fills the XCD's 32
+        // burst, silence, a write burst.  The second workgroup of every CU (the upper half of its XCD's slots: the dispatcher fills the XCD's
         // CUs once before it doubles up) starts late by g.persistent - 1 units of ~0.4 us, so that its stores fall under its
         // partner's loads; a persistent workgroup keeps that phase for its whole tile list.
-        if (slot >= 32)
+        if (slot >= (step >> 1))
             for (int d = 1; d < g.persistent; ++d) __builtin_amdgcn_s_sleep(16);
         prologue(std::true_type{}, i0, j0);
         for (;;) {
@@ -802,6 +802,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs g) {
     }
 }
 
+// two resident workgroups per CU, a multiple of the eight XCDs (512 on MI355X)
+inline int persistent_grid() { return (2 * cu_count()) & ~7; }
+
 template <typename TI, typename TO, bool AKM, bool BKM, int GATHER = 0, typename Cfg = Tile128>
 hipError_t launch(const GemmArgs& g_in, hipStream_t st) {
     GemmArgs g = g_in;
@@ -837,10 +840,10 @@ hipError_t launch(const GemmArgs& g_in, hipStream_t st) {
     g.epi_simple = g.act == kActNone && !g.aux && !g.zsave && !g.gate && !g.residual && !g.drop_thresh && !g.omap;
     // Persistent form for the token-matrix projections (65536 x {256..1024} x {256..1024}: thousands of tiles of 4 - 16 k-steps):
     // every tile interior and vector-addressable, at least two tiles per resident workgroup.  HVC_GEMM_PERSISTENT=0 disables (A/B).
-    const bool persistent_on = [] { const char* e = getenv("HVC_GEMM_PERSISTENT"); return !(e && e[0] == '0'); }();      // read per launch: the tests run both forms in one process
+    const bool persistent_on = option(kOptGemmPersistent) != 0;      // read per launch: the tests run both forms in one process
     using TA = OperandTile<TI, BK, AKM, kBM>;
     using TB = OperandTile<TI, BK, BKM, kBN>;
-    static const int stagger = [] { const char* e = getenv("HVC_GEMM_STAGGER"); return e ? atoi(e) : 0; }();
+    const int stagger = option(kOptGemmStagger) > 0 ? option(kOptGemmStagger) : 0;
     g.persistent = (1 + stagger) * (int)(persistent_on && GATHER == 0 && std::is_same_v<Cfg, Tile128> && g.splitk == 1 && tiles >= 1024 && TA::FULL && TB::FULL && g.vec_a && g.vec_b && g.vec_epi && !g.omap && (reinterpret_cast<uintptr_t>(g.bias) & 15) == 0 &&
                    g.M % kBM == 0 && g.N % kBN == 0 && g.K % BK == 0);
     if constexpr (GATHER == 0 && std::is_same_v<Cfg, Tile128>) {      // (measured on the 128 x 128 tile only)
@@ -851,7 +854,7 @@ hipError_t launch(const GemmArgs& g_in, hipStream_t st) {
                     if (e != hipSuccess) return e;
                     raised = true;
                 }
-                hipLaunchKernelGGL(kp, dim3(512), dim3(256), lds, st, g);
+                hipLaunchKernelGGL(kp, dim3(persistent_grid()), dim3(256), lds, st, g);
                 return hipGetLastError();
             };
             // the block's fused projections (training form: dropout on) on 128 x 128 tiles: static epilogues
@@ -893,7 +896,7 @@ hipError_t launch(const GemmArgs& g_in, hipStream_t st) {
 
 // HVC_GEMM_HALF_TILE=0 pins the 128 x 128 tile (A/B switch for scripts/gemm_vs_blas.py)
 inline bool use_half_tile(const GemmArgs& g) {
-    static const bool env_on = [] { const char* e = getenv("HVC_GEMM_HALF_TILE"); return !(e && e[0] == '0'); }();
+    const bool env_on = option(kOptGemmHalfTile) != 0;
     const int64_t tiles = (int64_t)((g.M + 127) / 128) * ((g.N + 127) / 128);
     if (!env_on || g.M <= 64) return false;
     if (gemm_workspace_floats(g.M, g.N, g.K) == 0) return tiles < 384;

@@ -6,6 +6,26 @@
 
 namespace hvc {
 
+// Run-time switches: kernel-form pins for A/B timing and for the parity tests that must reach every shipped instantiation.
+// Atomic ints read at launch (launches also come from torch's autograd worker thread, so a getenv() per launch would race with a
+// setenv() on the Python thread); the initial value of each is taken ONCE, when the library is loaded, from the environment
+// variable of the same name.  Set through the C ABI: hvc_set_option("HVC_ATTN_FWD_ROWS", 64).
+enum Option {
+    kOptAttnFwdRows = 0,     // HVC_ATTN_FWD_ROWS     0 = by size, 32 / 64 pin the forward kernel
+    kOptAttnFwdWaves,        // HVC_ATTN_FWD_WAVES    0 = by size, 4 / 8 pin the 64-row forward's workgroup form
+    kOptAttnBwdWaves,        // HVC_ATTN_BWD_WAVES    0 = by size, 4 / 8 pin the dQ and dK/dV workgroup form
+    kOptAttnExtraLds,        // HVC_ATTN_EXTRA_LDS    bytes added to every attention launch's LDS request (occupancy experiments)
+    kOptAttnFwdAsm,          // HVC_ATTN_FWD_ASM      1 = hand-placed steady-state forward where its shape conditions hold (default), 0 = C++ twin
+    kOptGemmPersistent,      // HVC_GEMM_PERSISTENT   1 = persistent token-matrix GEMMs (default), 0 = one tile per workgroup
+    kOptGemmStagger,         // HVC_GEMM_STAGGER      start-up stagger of the second workgroup of a CU (>= 0)
+    kOptGemmHalfTile,        // HVC_GEMM_HALF_TILE    1 = 64 x 128 tiles on shapes that under-fill the chip (default)
+    kOptFp8Mx,               // HVC_FP8_MX            1 = 32x32x64 f8f6f4 forward (round-3 experiment kernel)
+    kOptConvForceAddr64,     // HVC_CONV_FORCE_ADDR64 1 = 64-bit addressed gather on every convolution (test hook)
+    kOptCount
+};
+int option(Option o);
+int cu_count();              // compute units of the current device (cached)
+
 struct AttnArgs {
     const void *q, *k, *v;
     void* o;

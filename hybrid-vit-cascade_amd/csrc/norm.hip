@@ -238,7 +238,7 @@ __global__ __launch_bounds__(256) void gn_silu_bwd_reduce_kernel(const T* __rest
         for (int j = 0; j < 8; ++j) {
             const int c = c8 * 8 + j, g = c / cg;
             rs[j] = stats[2 * (b * G + g) + 1];
-            nm[j] = -stats[2 * (b * G + g)] * rs[j];
+            nm[j] = stats[2 * (b * G + g)];          // the mean itself: xhat = (x - mean) * rstd, the form the forward and dx kernels use
             gam[j] = gamma[c];
             bet[j] = beta[c];
         }
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(256) void gn_silu_bwd_reduce_kernel(const T* __rest
         load8<T>(db + (int64_t)p * C + c8 * 8, dv);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const float xh = fmaf(xv[j], rs[j], nm[j]);
+            const float xh = (xv[j] - nm[j]) * rs[j];      // not fma(x, rstd, -mean rstd): that cancels ~|mean| / std ulps when |mean| >> std
             const float ds = dv[j] * act_grad_f(fmaf(xh, gam[j], bet[j]), act);
             u[j] = ds;
             v[j] = ds * xh;

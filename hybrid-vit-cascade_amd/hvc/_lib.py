@@ -22,6 +22,9 @@ SIGNATURES = {
     "hvc_last_error": (C.c_char_p, []),
     "hvc_set_seed_counter": (_i, [_p]),
     "hvc_seed_counter_advance": (_i, [_p, C.c_uint32, _p]),
+    "hvc_clear_seed_counter_if": (_i, [_p]),
+    "hvc_set_option": (_i, [C.c_char_p, _i]),
+    "hvc_get_option": (_i, [C.c_char_p, C.POINTER(_i)]),
     "hvc_device_info": (_i, [C.POINTER(_i), C.POINTER(_i), C.c_char_p, _i]),
     "hvc_attention_fwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i] + [_i64] * 12 + [_f, _f, _u64, _i, _p]),
     "hvc_attention_fwd_fp8_workspace": (_i64, [_i, _i, _i, _i]),

@@ -34,21 +34,36 @@ def set_fp8_attention(on: bool) -> None:
 CHECKPOINT_POLICY = "auto"
 
 
-def set_checkpoint_policy(policy: str) -> None:
+def set_checkpoint_policy(policy) -> None:
+    """'auto' | 'on' | 'off'; JSON booleans are accepted too (true = 'on', the reference's behaviour; false = 'off')."""
     global CHECKPOINT_POLICY
+    if isinstance(policy, bool):
+        policy = "on" if policy else "off"
     if policy not in ("auto", "on", "off"):
-        raise ValueError("checkpoint policy must be 'auto', 'on' or 'off'")
+        raise ValueError("checkpoint policy must be 'auto', 'on' or 'off' (or a boolean)")
     CHECKPOINT_POLICY = policy
+    _CHECKPOINT_DECISIONS.clear()
+
+
+_CHECKPOINT_DECISIONS = {}      # (device, saved_bytes) -> bool: 'auto' decides once per module shape, not once per forward
 
 
 def use_checkpoint(requested: bool, saved_bytes: int, device) -> bool:
-    """Should a module that was asked to checkpoint (requested) really recompute?  saved_bytes = what it would keep otherwise."""
+    """Should a module that was asked to checkpoint (requested) really recompute?  saved_bytes = what it would keep otherwise.
+    'auto' compares with the memory this process can still get: the driver's free figure PLUS what torch's caching allocator
+    holds but has not handed out (mem_get_info alone under-reports after the first steps and could flip the answer mid-run or
+    differ between DDP ranks); the answer is cached per (device, size), so there is one driver query per shape, not per step."""
     if not requested or CHECKPOINT_POLICY == "off":
         return False
     if CHECKPOINT_POLICY == "on" or not torch.cuda.is_available():
         return True
-    free, _total = torch.cuda.mem_get_info(device)
-    return 4 * saved_bytes > free          # auto: recompute only if four times the saved activations would not fit
+    key = (str(device), int(saved_bytes))
+    hit = _CHECKPOINT_DECISIONS.get(key)
+    if hit is None:
+        free, _total = torch.cuda.mem_get_info(device)
+        free += torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device)
+        hit = _CHECKPOINT_DECISIONS[key] = 4 * saved_bytes > free      # recompute only if four times the saved activations would not fit
+    return hit
 
 
 def _fp8(t) -> bool:

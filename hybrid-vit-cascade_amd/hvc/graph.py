@@ -60,12 +60,28 @@ class GraphedStep:
     def __call__(self, *inputs):
         if self._closed:
             raise RuntimeError("GraphedStep was closed")
+        from . import functional as F
         for ref, attr, dst in self._pinned:
             prm = ref()
             hit = getattr(prm, attr, None) if prm is not None else None
             if hit is None or hit[1] is not dst:
                 raise RuntimeError("a cached weight copy captured by this graph was rebuilt (parameters re-cast or reloaded "
                                    "since the capture): build a new GraphedStep")
+            # Same buffer, but is its CONTENT still the parameter's?  load_state_dict / copy_ into the parameter bumps its
+            # version, invalidate_param_casts() the epoch: without an eager forward in between nothing has re-cast the copy, and
+            # the captured forward would read pre-load weights for one whole step (the in-graph refresh runs after the
+            # backward).  The graph only knows the buffer's address, so refill it in place and re-key it.
+            key = hit[0]
+            if key[:4] != (prm._version, F._CAST_EPOCH, prm.device, prm.data_ptr()):
+                if prm.device != dst.device:
+                    raise RuntimeError("a parameter captured by this graph moved to another device: build a new GraphedStep")
+                with torch.no_grad():
+                    if attr == "_hvc_cast":
+                        dst.copy_(prm.detach())
+                    else:
+                        F._CONV_FILL[attr](dst, prm)
+                setattr(prm, attr, (F._cache_key(prm, *key[4:]), dst))
+                F._register(prm, attr)
         for dst, src in zip(self.static_inputs, inputs):
             if dst.data_ptr() != src.data_ptr():
                 dst.copy_(src, non_blocking=True)
@@ -78,7 +94,8 @@ class GraphedStep:
         if getattr(self, "_closed", True):      # never opened (the constructor failed early) or closed already
             return
         self._closed = True
-        _lib.check(self.lib.hvc_set_seed_counter(None), "hvc_set_seed_counter")
+        # only if the library still reads THIS object's counter: a newer GraphedStep may have installed its own since
+        _lib.check(self.lib.hvc_clear_seed_counter_if(self.counter.data_ptr()), "hvc_clear_seed_counter_if")
 
     def __enter__(self):
         return self

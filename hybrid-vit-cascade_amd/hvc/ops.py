@@ -42,6 +42,36 @@ class _Timed:
         return False
 
 
+def set_option(name: str, value: int) -> None:
+    """Run-time switch of the library (include/hvc_hip.h: hvc_set_option), e.g. set_option("HVC_ATTN_FWD_ROWS", 64)."""
+    check(_lib.load().hvc_set_option(name.encode(), int(value)), "hvc_set_option")
+
+
+def get_option(name: str) -> int:
+    import ctypes as C
+    v = C.c_int()
+    check(_lib.load().hvc_get_option(name.encode(), C.byref(v)), "hvc_get_option")
+    return v.value
+
+
+class options:
+    """`with ops.options(HVC_ATTN_FWD_ROWS=64, HVC_ATTN_BWD_WAVES=4): ...` - sets the switches, restores the old values on exit."""
+
+    def __init__(self, **kv):
+        self.kv, self.old = kv, {}
+
+    def __enter__(self):
+        for k, v in self.kv.items():
+            self.old[k] = get_option(k)
+            set_option(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.old.items():
+            set_option(k, v)
+        return False
+
+
 def _code(dtype):
     try:
         return _DT[dtype]
@@ -110,8 +140,12 @@ def attention_fwd(q, k, v, scale, p_drop=0.0, seed=0, fp8=False):
                 float(scale), float(p_drop), int(seed), _stream()), "hvc_attention_fwd_fp8")
         return o, lse
     # the library runs the 64-rows-per-wave kernel from 512 workgroups up (csrc/attention.hip launch_fwd): label the timing so
-    two_blocks = q.dtype == torch.bfloat16 and ((Nq + 255) // 256) * B * H >= 512 and os.environ.get("HVC_ATTN_FWD_ROWS") != "32"
-    with _Timed("attn_fwd2_kernel" if two_blocks or os.environ.get("HVC_ATTN_FWD_ROWS") == "64" else "attn_fwd_kernel", 4.0 * B * H * Nq * Nk * D):
+    label = "attn_fwd_kernel"
+    if PROFILE is not None:
+        rows_pin = get_option("HVC_ATTN_FWD_ROWS")
+        if rows_pin == 64 or (rows_pin != 32 and q.dtype == torch.bfloat16 and ((Nq + 255) // 256) * B * H >= 512):
+            label = "attn_fwd2_kernel"
+    with _Timed(label, 4.0 * B * H * Nq * Nk * D):
       check(_lib.load().hvc_attention_fwd(
         q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse.data_ptr(), B, H, Nq, Nk, D,
         *_bnhd_strides(q), *_bnhd_strides(k), *_bnhd_strides(v), *_bnhd_strides(o),

@@ -49,6 +49,19 @@ const char* hvc_last_error(void);
  * counter the forward saw.  (The reference draws its masks from torch's Philox stream: train_direct_4gpu.py:65-71.) */
 int hvc_set_seed_counter(const uint32_t* device_counter);
 int hvc_seed_counter_advance(uint32_t* device_counter, uint32_t step, void* stream);
+/* Detaches the counter only if the library still points at `device_counter` (compare-and-swap): the finaliser of an older
+ * graphed step must not detach the counter a newer one has installed.  Returns 0 either way. */
+int hvc_clear_seed_counter_if(const uint32_t* device_counter);
+
+/* Run-time switches of the library (kernel-form pins for A/B timing and for parity tests that must reach every shipped
+ * instantiation of a kernel; no reference counterpart - the reference has one code path per op).  Names are those of the
+ * environment variables that give the initial values when the library is loaded: HVC_ATTN_FWD_ROWS (0 | 32 | 64),
+ * HVC_ATTN_FWD_WAVES (0 | 4 | 8), HVC_ATTN_BWD_WAVES (0 | 4 | 8), HVC_ATTN_FWD_ASM (1 | 0), HVC_ATTN_EXTRA_LDS (bytes),
+ * HVC_GEMM_PERSISTENT (1 | 0), HVC_GEMM_STAGGER (>= 0), HVC_GEMM_HALF_TILE (1 | 0), HVC_FP8_MX (0 | 1),
+ * HVC_CONV_FORCE_ADDR64 (0 | 1).  Values are atomic ints read at launch time, safe to set from any thread between launches;
+ * unknown names and negative values return HVC_E_BADARG. */
+int hvc_set_option(const char* name, int value);
+int hvc_get_option(const char* name, int* value);
 
 /* Fills CU count and wavefront size of the current device and its gcnArchName; 0 on success. */
 int hvc_device_info(int* cu_count, int* wavefront, char* arch, int arch_len);

@@ -29,13 +29,27 @@ Params = Dict[str, torch.Tensor]
 CHUNK_CHECKPOINT = False      # attention_core: checkpoint every q_chunk slab (set by the 128^3 fixture generator only)
 
 
+def dropout(x: torch.Tensor, p: float, keep: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """nn.Dropout(p) in train mode (torch/nn/functional.py dropout: x * mask / (1 - p)).  keep = None draws torch's own mask as
+    the reference does; a GIVEN keep mask (0/1, shape of x) is used by the dropout-on parity tests, which feed the oracle the
+    mask the HIP kernels drew (recovered from kernel outputs: tests/test_gpu_dropout_parity.py) - same formula, that mask
+    (tests/test_oracle_golden.py checks it reproduces F.dropout bit for bit on torch's own mask)."""
+    if keep is None:
+        return F.dropout(x, p, p > 0)
+    return x * (keep.to(x.dtype) / (1.0 - p))       # ATen's order: the mask is divided by (1 - p), then multiplied in
+
+
 def attention_core(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float,
-                   q_chunk: Optional[int] = None, p_drop: float = 0.0) -> torch.Tensor:
+                   q_chunk: Optional[int] = None, p_drop: float = 0.0, keep: Optional[torch.Tensor] = None) -> torch.Tensor:
     """softmax(q k^T * scale) v on (B, h, N, d) operands -- models/vit_components.py:46-51 and
     :103-113.  p_drop > 0 draws the reference's attn_drop mask on the probabilities (:48, :110; torch's
-    generator, so the masks are torch's, as in the reference's train mode); parity tests use p_drop = 0.
+    generator, so the masks are torch's, as in the reference's train mode), or applies the given (B, h, Nq, Nk)
+    keep mask (see dropout()).
     q_chunk bounds the materialised score slab so N = 32768 stays tractable on the CPU (identical
     arithmetic per row)."""
+    if keep is not None:
+        attn = (q @ k.transpose(-2, -1)) * scale
+        return dropout(attn.softmax(dim=-1), p_drop, keep) @ v
     if q_chunk is None or q.shape[-2] <= q_chunk:
         attn = (q @ k.transpose(-2, -1)) * scale
         return F.dropout(attn.softmax(dim=-1), p_drop, p_drop > 0) @ v
@@ -55,28 +69,29 @@ def attention_core(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: flo
 
 
 def self_attention(x: torch.Tensor, P: Params, pre: str, num_heads: int,
-                   q_chunk: Optional[int] = None, p_drop: float = 0.0) -> torch.Tensor:
+                   q_chunk: Optional[int] = None, p_drop: float = 0.0, keeps=(None, None)) -> torch.Tensor:
     """MultiHeadSelfAttention.forward, models/vit_components.py:31-57 (p_drop = 0: eval; > 0: attn_drop :48
-    and proj_drop :55).  qkv columns are laid out [q(h,d) | k(h,d) | v(h,d)] (:41-43)."""
+    and proj_drop :55).  qkv columns are laid out [q(h,d) | k(h,d) | v(h,d)] (:41-43).
+    keeps = (attention-probability keep mask, proj-output keep mask) or Nones (torch's masks)."""
     B, N, Cn = x.shape
     d = Cn // num_heads
     qkv = F.linear(x, P[pre + "qkv.weight"]).reshape(B, N, 3, num_heads, d).permute(2, 0, 3, 1, 4)
-    o = attention_core(qkv[0], qkv[1], qkv[2], d ** -0.5, q_chunk, p_drop)
+    o = attention_core(qkv[0], qkv[1], qkv[2], d ** -0.5, q_chunk, p_drop, keeps[0])
     o = o.transpose(1, 2).reshape(B, N, Cn)
-    return F.dropout(F.linear(o, P[pre + "proj.weight"], P[pre + "proj.bias"]), p_drop, p_drop > 0)
+    return dropout(F.linear(o, P[pre + "proj.weight"], P[pre + "proj.bias"]), p_drop, keeps[1])
 
 
 def cross_attention(x: torch.Tensor, ctx: torch.Tensor, P: Params, pre: str, num_heads: int,
-                    q_chunk: Optional[int] = None, p_drop: float = 0.0) -> torch.Tensor:
-    """MultiHeadCrossAttention.forward, models/vit_components.py:84-119 (p_drop as in self_attention: :110, :117)."""
+                    q_chunk: Optional[int] = None, p_drop: float = 0.0, keeps=(None, None)) -> torch.Tensor:
+    """MultiHeadCrossAttention.forward, models/vit_components.py:84-119 (p_drop / keeps as in self_attention: :110, :117)."""
     B, N, Cn = x.shape
     M = ctx.shape[1]
     d = Cn // num_heads
     q = F.linear(x, P[pre + "q.weight"]).reshape(B, N, num_heads, d).permute(0, 2, 1, 3)
     kv = F.linear(ctx, P[pre + "kv.weight"]).reshape(B, M, 2, num_heads, d).permute(2, 0, 3, 1, 4)
-    o = attention_core(q, kv[0], kv[1], d ** -0.5, q_chunk, p_drop)
+    o = attention_core(q, kv[0], kv[1], d ** -0.5, q_chunk, p_drop, keeps[0])
     o = o.transpose(1, 2).reshape(B, N, Cn)
-    return F.dropout(F.linear(o, P[pre + "proj.weight"], P[pre + "proj.bias"]), p_drop, p_drop > 0)
+    return dropout(F.linear(o, P[pre + "proj.weight"], P[pre + "proj.bias"]), p_drop, keeps[1])
 
 
 def adaln_params(cond: torch.Tensor, P: Params, pre: str) -> Tuple[torch.Tensor, ...]:
@@ -98,23 +113,27 @@ def sinusoidal_time_embedding(t: torch.Tensor, embed_dim: int) -> torch.Tensor:
 # ViT block / backbone  (models/hybrid_vit_backbone.py)
 # ------------------------------------------------------------------------------------------------
 def vit_block(x: torch.Tensor, ctx: torch.Tensor, cond: torch.Tensor, P: Params, pre: str,
-              num_heads: int, q_chunk: Optional[int] = None, p_drop: float = 0.0) -> torch.Tensor:
+              num_heads: int, q_chunk: Optional[int] = None, p_drop: float = 0.0, keeps: Optional[dict] = None) -> torch.Tensor:
     """HybridViTBlock3D.forward with use_prev_stage=False, return_attention=False,
     models/hybrid_vit_backbone.py:88-143 (p_drop > 0: the train-mode nn.Dropout draws of :77, :79 and of the
-    attention modules)."""
+    attention modules).  keeps: optional given keep masks {"sa_attn", "sa_proj", "ca_attn", "ca_proj", "fc1", "fc2"}
+    in place of torch's draws (see dropout())."""
     Cn = x.shape[-1]
+    kp = keeps or {}
     shift_sa, scale_sa, gate_sa, shift_mlp, scale_mlp, gate_mlp = adaln_params(cond, P, pre + "adaln.")
     h = F.layer_norm(x, (Cn,), P[pre + "norm1.weight"], P[pre + "norm1.bias"], 1e-5)          # :120
     h = (1 + scale_sa) * h + shift_sa                                                          # :121
-    x = x + gate_sa * self_attention(h, P, pre + "self_attn.", num_heads, q_chunk, p_drop)     # :122-123
+    x = x + gate_sa * self_attention(h, P, pre + "self_attn.", num_heads, q_chunk, p_drop,
+                                     (kp.get("sa_attn"), kp.get("sa_proj")))                   # :122-123
     h = F.layer_norm(x, (Cn,), P[pre + "norm2.weight"], P[pre + "norm2.bias"], 1e-5)          # :126
-    x = x + cross_attention(h, ctx, P, pre + "cross_attn.", num_heads, q_chunk, p_drop)        # :127-128
+    x = x + cross_attention(h, ctx, P, pre + "cross_attn.", num_heads, q_chunk, p_drop,
+                            (kp.get("ca_attn"), kp.get("ca_proj")))                             # :127-128
     h = F.layer_norm(x, (Cn,), P[pre + "norm3.weight"], P[pre + "norm3.bias"], 1e-5)          # :136
     h = (1 + scale_mlp) * h + shift_mlp                                                        # :137
     h = F.linear(h, P[pre + "mlp.0.weight"], P[pre + "mlp.0.bias"])                            # :75
-    h = F.dropout(F.gelu(h), p_drop, p_drop > 0)                                               # :76 exact erf, :77
+    h = dropout(F.gelu(h), p_drop, kp.get("fc1"))                                              # :76 exact erf, :77
     h = F.linear(h, P[pre + "mlp.3.weight"], P[pre + "mlp.3.bias"])                            # :78
-    return x + gate_mlp * F.dropout(h, p_drop, p_drop > 0)                                     # :79, :139
+    return x + gate_mlp * dropout(h, p_drop, kp.get("fc2"))                                    # :79, :139
 
 
 def voxel_embed_plan(volume_size: Sequence[int], in_channels: int, voxel_dim: int,

@@ -134,3 +134,19 @@ def golden():
             cache[name] = Golden(name)
         return cache[name]
     return get
+
+
+@pytest.fixture
+def hvc_option():
+    """Setter for the library's run-time switches (hvc_set_option); every switch touched is restored after the test.  Replaces
+    monkeypatch.setenv on HVC_* names: the library reads its switches from atomics, not from the environment, at launch."""
+    from hvc import ops
+    old = {}
+
+    def set_(name, value):
+        if name not in old:
+            old[name] = ops.get_option(name)
+        ops.set_option(name, int(value))
+    yield set_
+    for name, value in old.items():
+        ops.set_option(name, value)

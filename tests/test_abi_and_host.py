@@ -347,3 +347,41 @@ def test_every_optimizer_step_invalidates_the_weight_cast_cache():
         key0 = HF._cache_key(p, torch.bfloat16)
         opt.step()
         assert HF._cache_key(p, torch.bfloat16) != key0, kw
+
+
+def test_checkpoint_policy_accepts_json_booleans_and_decides_once():
+    """"gradient_checkpointing": true / false in the JSON config map to 'on' / 'off'; anything else still raises."""
+    from hvc import functional as HF
+    try:
+        HF.set_checkpoint_policy(True)
+        assert HF.CHECKPOINT_POLICY == "on" and HF.use_checkpoint(True, 1, "cpu") and not HF.use_checkpoint(False, 1, "cpu")
+        HF.set_checkpoint_policy(False)
+        assert HF.CHECKPOINT_POLICY == "off" and not HF.use_checkpoint(True, 1 << 50, "cpu")
+        with pytest.raises(ValueError):
+            HF.set_checkpoint_policy("sometimes")
+    finally:
+        HF.set_checkpoint_policy("auto")
+
+
+def test_options_are_declared_in_the_header_and_bound():
+    """hvc_set_option / hvc_get_option replace per-launch getenv() reads: declared in include/hvc_hip.h, exported by the
+    library, unknown names refused, values round-trip, the environment only seeds the initial value."""
+    import ctypes as C
+    from hvc import _lib, ops
+    lib = _lib.load()
+    hdr = open(os.path.join(ROOT, "include", "hvc_hip.h")).read()
+    for name in ("HVC_ATTN_FWD_ROWS", "HVC_ATTN_FWD_WAVES", "HVC_ATTN_BWD_WAVES", "HVC_ATTN_FWD_ASM", "HVC_GEMM_PERSISTENT",
+                 "HVC_GEMM_STAGGER", "HVC_GEMM_HALF_TILE", "HVC_FP8_MX", "HVC_CONV_FORCE_ADDR64", "HVC_ATTN_EXTRA_LDS"):
+        assert name in hdr, name
+        old = ops.get_option(name)
+        with ops.options(**{name: 4}):
+            assert ops.get_option(name) == 4
+        assert ops.get_option(name) == old
+    assert lib.hvc_set_option(b"HVC_NO_SUCH_SWITCH", 1) != 0
+    assert lib.hvc_set_option(b"HVC_GEMM_STAGGER", -3) != 0          # a negative stagger used to disable the persistent form silently
+    v = C.c_int(-1)
+    assert lib.hvc_get_option(b"HVC_GEMM_PERSISTENT", C.byref(v)) == 0 and v.value == 1
+    csrc = os.path.join(ROOT, "hybrid-vit-cascade_amd", "csrc")
+    for f in os.listdir(csrc):
+        if f.endswith(".hip") and f != "capi.hip":
+            assert "getenv" not in open(os.path.join(csrc, f)).read(), f"{f}: launch paths must read hvc::option(), not the environment"

@@ -515,7 +515,7 @@ def test_attention_is_bit_reproducible_with_dropout(shape, dtype):
 
 
 @pytest.mark.parametrize("kind", ["plain", "bias", "dx", "fc1", "fc2_dx", "proj", "cross_proj"])
-def test_gemm_persistent_static_epilogues_match_the_generic_kernel(kind, monkeypatch):
+def test_gemm_persistent_static_epilogues_match_the_generic_kernel(kind, hvc_option):
     """Token-matrix GEMMs (>= 1024 interior 128 x 128 tiles) run as persistent workgroups with straight-line epilogues - one per fused
     projection of the block (round 3).  Same k loop, same epilogue arithmetic in the same order as the generic one-tile-per-workgroup kernel
     (HVC_GEMM_PERSISTENT=0), so every output (C, saved pre-activation, zsave) must agree bit for bit (up to per-instantiation FMA
@@ -550,7 +550,7 @@ def test_gemm_persistent_static_epilogues_match_the_generic_kernel(kind, monkeyp
     pre_in = rnd(M, N) if "aux_in" in extra else None
     outs = {}
     for form in ("0", "1"):
-        monkeypatch.setenv("HVC_GEMM_PERSISTENT", form)
+        hvc_option("HVC_GEMM_PERSISTENT", form)
         call = dict(kw)
         side = None
         if "aux" in extra:
@@ -577,7 +577,7 @@ def test_gemm_persistent_static_epilogues_match_the_generic_kernel(kind, monkeyp
 
 
 @pytest.mark.parametrize("shape", [(2, 4, 700, 515, 0.1), (1, 2, 1500, 97, 0.0), (2, 2, 513, 4096, 0.25)])
-def test_attention_forward_eight_wavefront_workgroups_match_four(shape, monkeypatch):
+def test_attention_forward_eight_wavefront_workgroups_match_four(shape, hvc_option):
     """The 64-row forward kernel (d = 64) has a 512-row form (eight wavefronts, one workgroup per CU; picked by problem size, here pinned
     through HVC_ATTN_FWD_WAVES): same arithmetic per wavefront, so output and log-sum-exp must be bit-identical on ragged shapes,
     with and without dropout."""
@@ -588,17 +588,17 @@ def test_attention_forward_eight_wavefront_workgroups_match_four(shape, monkeypa
     q = torch.randn(B, Nq, H, D, generator=g).to(dev(), torch.bfloat16)
     k = torch.randn(B, Nk, H, D, generator=g).to(dev(), torch.bfloat16)
     v = torch.randn(B, Nk, H, D, generator=g).to(dev(), torch.bfloat16)
-    monkeypatch.setenv("HVC_ATTN_FWD_ROWS", "64")
+    hvc_option("HVC_ATTN_FWD_ROWS", "64")
     outs = {}
     for waves in ("4", "8"):
-        monkeypatch.setenv("HVC_ATTN_FWD_WAVES", waves)
+        hvc_option("HVC_ATTN_FWD_WAVES", waves)
         outs[waves] = ops.attention_fwd(q, k, v, D ** -0.5, p, 33)
     assert torch.isfinite(outs["8"][0].float()).all()
     assert torch.equal(outs["4"][0], outs["8"][0]) and torch.equal(outs["4"][1], outs["8"][1])
 
 
 @pytest.mark.parametrize("shape", [(2, 4, 700, 515, 64, 0.1), (1, 8, 1030, 1100, 32, 0.1), (2, 2, 256, 4096, 64, 0.0), (1, 2, 65, 257, 32, 0.25)])
-def test_attention_backward_eight_wavefront_workgroups_match_four(shape, monkeypatch):
+def test_attention_backward_eight_wavefront_workgroups_match_four(shape, hvc_option):
     """The dQ and dK/dV kernels have a 256-row / 256-key form (eight wavefronts, one workgroup per CU; picked by problem size, here
     pinned through HVC_ATTN_BWD_WAVES).  A wavefront does the same arithmetic in the same order in both forms, so the gradients
     must be bit-identical - ragged sizes, both head dims, with and without dropout (the 4-wavefront form is the one the oracle
@@ -613,7 +613,7 @@ def test_attention_backward_eight_wavefront_workgroups_match_four(shape, monkeyp
     o, lse = ops.attention_fwd(q, k, v, D ** -0.5, p, 21)
     grads = {}
     for waves in ("4", "8"):
-        monkeypatch.setenv("HVC_ATTN_BWD_WAVES", waves)
+        hvc_option("HVC_ATTN_BWD_WAVES", waves)
         grads[waves] = ops.attention_bwd(q, k, v, o, do, lse, D ** -0.5, p, 21)
     for name, a, b in zip(("dq", "dk", "dv"), grads["4"], grads["8"]):
         assert torch.isfinite(b.float()).all(), name
@@ -1553,7 +1553,7 @@ def test_ssim_l1_loss_random_sizes_and_weights(seed):
 
 
 @pytest.mark.parametrize("seed", range(8))
-def test_attention_forward_64_row_kernel_matches_oracle_and_32_row_kernel(seed, monkeypatch):
+def test_attention_forward_64_row_kernel_matches_oracle_and_32_row_kernel(seed, hvc_option):
     """attn_fwd2_kernel (two query blocks per wavefront, 32-key tiles; picked automatically from 512 workgroups up) pinned
     through HVC_ATTN_FWD_ROWS on small ragged shapes: output and log-sum-exp against the oracle, the same dropout mask as the
     32-row kernel (zero pattern of O for one-hot V), a late spike that forces the deferred rescale, packed strides, and
@@ -1573,7 +1573,7 @@ def test_attention_forward_64_row_kernel_matches_oracle_and_32_row_kernel(seed, 
     rel = lambda a, b: ((a.float().cpu() - b.float().cpu()).abs().max() / max(b.float().abs().max().item(), 1.0)).item()
     out = {}
     for rows in ("32", "64"):
-        monkeypatch.setenv("HVC_ATTN_FWD_ROWS", rows)
+        hvc_option("HVC_ATTN_FWD_ROWS", rows)
         o, lse = ops.attention_fwd(q, k, v, D ** -0.5)
         assert rel(o, ref) < 3e-2, (rows, B, H, N, M, D)
         od, lsed = ops.attention_fwd(q, k, v, D ** -0.5, 0.25, 99 + seed)
@@ -1588,10 +1588,10 @@ def test_attention_forward_64_row_kernel_matches_oracle_and_32_row_kernel(seed, 
         eye[:, torch.arange(M), :, torch.arange(M)] = 1
         masks = []
         for rows in ("32", "64"):
-            monkeypatch.setenv("HVC_ATTN_FWD_ROWS", rows)
+            hvc_option("HVC_ATTN_FWD_ROWS", rows)
             masks.append(ops.attention_fwd(q, k, eye, D ** -0.5, 0.25, 99 + seed)[0] != 0)
         assert torch.equal(masks[0], masks[1])
-    monkeypatch.setenv("HVC_ATTN_FWD_ROWS", "64")
+    hvc_option("HVC_ATTN_FWD_ROWS", "64")
     o, lse = out["64"][2], out["64"][3]
     do = torch.randn(B, N, H, D, generator=rng).to(dev(), torch.bfloat16)
     _, _, dv = ops.attention_bwd(q, k, v, o, do, lse, D ** -0.5, 0.25, 99 + seed)
@@ -2210,10 +2210,58 @@ def test_graphed_train_step_matches_eager_and_draws_fresh_dropout_masks():
         assert torch.equal(w1[k], w2[k]), k
 
 
+def test_graphed_step_after_load_state_dict_and_counter_ownership():
+    """(a) a replay right after load_state_dict (no eager forward in between) must run on the LOADED weights - the
+    graph holds the addresses of the cached bf16 / conv-layout copies, whose keys went stale with the load; (b) closing an OLDER
+    GraphedStep must not detach the seed counter a newer one installed."""
+    from direct_regression.model_direct import DirectCTRegression, DirectRegressionLoss
+    from hvc import _lib, synthetic
+    from hvc.graph import GraphedStep
+    import ctypes as C
+    cfg = dict(volume_size=(16, 16, 16), xray_img_size=64, voxel_dim=64, vit_depth=1, num_heads=2, xray_feature_dim=32)
+    xr, ct = synthetic.batch(3, 2, cfg["volume_size"], cfg["xray_img_size"], device="cuda:0")
+    crit = DirectRegressionLoss(1.0, 0.5)
+    torch.manual_seed(0)
+    m = DirectCTRegression(**cfg).to(dev()).eval()                  # eval: no dropout, running BN statistics -> deterministic forward
+    torch.manual_seed(1)
+    other = DirectCTRegression(**cfg).to(dev()).eval()
+    gen = torch.Generator().manual_seed(9)
+    with torch.no_grad():
+        for mod in (m, other):
+            for blk in mod.vit_backbone.blocks:
+                blk.adaln.linear.weight.copy_(torch.randn(blk.adaln.linear.weight.shape, generator=gen) * 0.02)
+
+    def fwd(a, b):
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+            return crit(m(a).float(), b)["total_loss"]
+
+    g = GraphedStep(fwd, [xr, ct], warmup=1)
+    try:
+        before = g(xr, ct).item()
+        m.load_state_dict(other.state_dict())                         # bumps every parameter's version; no eager forward follows
+        got = g(xr, ct).item()
+        want = fwd(xr, ct).item()                                     # eager: re-casts lazily, certainly on the new weights
+        assert got == want and got != before, (before, got, want)
+        # (b) an older object's finaliser vs a newer object's counter
+        lib = _lib.load()
+        g2 = GraphedStep(fwd, [xr, ct], warmup=1)
+        try:
+            g.close()                                                 # older one goes away AFTER the newer one took over
+            probe = torch.zeros(1, dtype=torch.int32, device=dev())
+            lib.hvc_clear_seed_counter_if(probe.data_ptr())          # a stranger's pointer: no effect either
+            # the newer graph still sees its own counter: its captured advance node and kernels agree -> replays stay valid
+            assert g2(xr, ct).item() == want
+            assert g2.counter.item() >= 2
+        finally:
+            g2.close()
+    finally:
+        g.close()
+
+
 @pytest.mark.parametrize("shape", [(2, 4, 512, 512, 64, 0.0), (1, 8, 1100, 130, 32, 0.0), (1, 2, 65, 257, 64, 0.0), (2, 8, 2048, 1024, 32, 0.1),
                                    (1, 4, 4096, 4096, 64, 0.1)])
 @pytest.mark.parametrize("variant", ["x16", "x64"])
-def test_attention_fp8_forward_vs_oracle_and_bf16_kernel(shape, variant, monkeypatch):
+def test_attention_fp8_forward_vs_oracle_and_bf16_kernel(shape, variant, hvc_option):
     """fp8 (e4m3) MFMA attention forward (BASELINE configs[4]; hvc_attention_fwd_fp8) against the fp64 softmax and the bf16
     kernel.  Stated tolerance: relative Frobenius error <= 6e-2 on O for WHITE-NOISE operands - e4m3 keeps 3 mantissa bits
     (rms rounding error 3.7 %), P and V are both rounded, and with zero-mean random V the output is itself a noise average, so
@@ -2222,7 +2270,7 @@ def test_attention_fp8_forward_vs_oracle_and_bf16_kernel(shape, variant, monkeyp
     bf16 kernel, and a backward pass (bf16 kernels on the fp8 forward's o / lse) within 8e-2 of the all-bf16 gradients.
     variant x64 = the round-3 experiment kernel (HVC_FP8_MX=1: 32x32x64 products, reference moved by a vote on the row sums)."""
     from hvc import ops
-    monkeypatch.setenv("HVC_FP8_MX", "1" if variant == "x64" else "0")
+    hvc_option("HVC_FP8_MX", 1 if variant == "x64" else 0)
     B, H, Nq, Nk, D, p = shape
     g = torch.Generator().manual_seed(Nq * 7 + Nk + D)
     q, k, v, do = (torch.randn(B, n, H, D, generator=g).to(dev(), torch.bfloat16) for n in (Nq, Nk, Nk, Nq))
@@ -2248,13 +2296,13 @@ def test_attention_fp8_forward_vs_oracle_and_bf16_kernel(shape, variant, monkeyp
 
 @pytest.mark.parametrize("variant", ["x16", "x64"])
 @pytest.mark.parametrize("case", ["flat", "ramp_up", "ramp_down", "huge"])
-def test_attention_fp8_reference_tracking_cases(case, variant, monkeypatch):
+def test_attention_fp8_reference_tracking_cases(case, variant, hvc_option):
     """Score patterns that stress how the fp8 kernels keep their scaled probabilities inside e4m3: flat rows (every probability
     equals the reference: the x64 kernel's row-sum vote must stay silent and the result is the mean of V), scores that climb
     tile after tile (the reference has to move again and again), scores that fall (small probabilities against an early
     maximum) and scores large enough to overflow exp2 against a stale reference.  fp64 softmax, fp8 tolerance (6e-2)."""
     from hvc import ops
-    monkeypatch.setenv("HVC_FP8_MX", "1" if variant == "x64" else "0")
+    hvc_option("HVC_FP8_MX", 1 if variant == "x64" else 0)
     B, H, Nq, Nk, D = 1, 2, 256, 1024 + 37, 32
     g = torch.Generator().manual_seed(17)
     q = torch.randn(B, Nq, H, D, generator=g)

@@ -302,3 +302,26 @@ def test_direct128_probe_fixture_matches_the_seeded_model(golden):
     for k in g.z.files:
         assert np.isfinite(g.z[k]).all(), k
     assert abs(float(g.z["loss/total_loss"]) - (float(g.z["loss/l1_loss"]) + 0.5 * float(g.z["loss/ssim_loss"]))) < 1e-6
+
+
+def test_oracle_dropout_with_a_given_mask_is_torch_dropout_with_that_mask():
+    """oracle.dropout(x, p, keep) is what the dropout-on GPU parity tests feed the kernels' recovered masks through: with the
+    mask torch itself drew (read off the zeros of F.dropout's output) it must reproduce F.dropout bit for bit - the formula of
+    nn.Dropout in train mode (reference: models/vit_components.py:48, :55; models/hybrid_vit_backbone.py:77, :79)."""
+    import torch.nn.functional as F
+    from oracle import hvc_oracle as O
+    torch.manual_seed(3)
+    x = torch.randn(7, 33, 5) + 3.0                       # no exact zeros in x
+    for p in (0.1, 0.25, 0.5):
+        y = F.dropout(x, p, True)
+        keep = y != 0
+        assert torch.equal(O.dropout(x, p, keep), y)
+        assert torch.allclose(O.dropout(x.double(), p, keep), y.double(), rtol=1e-6)
+    # attention_core with torch's own mask recovered the same way == the unmasked-path call under the same generator state
+    q, k, v = (torch.randn(1, 2, 9, 8) for _ in range(3))
+    torch.manual_seed(11)
+    ref = O.attention_core(q, k, v, 8 ** -0.5, p_drop=0.25)
+    torch.manual_seed(11)
+    probs = ((q @ k.transpose(-2, -1)) * 8 ** -0.5).softmax(dim=-1)
+    keep = F.dropout(probs, 0.25, True) != 0
+    assert torch.allclose(O.attention_core(q, k, v, 8 ** -0.5, p_drop=0.25, keep=keep), ref, atol=1e-6)
