@@ -213,7 +213,12 @@ def main():
     ap.add_argument("--graph", default="auto", choices=("auto", "on", "off"),
                     help="replay the step as one captured hipGraph (auto: for the launch-bound direct64 workload, single GPU)")
     ap.add_argument("--no-extra", action="store_true", help="skip the short 64^3 / 256^3 runs reported under other_resolutions")
+    ap.add_argument("--ddp", action="store_true",
+                    help="with --gpus 1: still initialise the nccl (= RCCL) process group (world size 1) and wrap the model in DDP, so that "
+                         "the multi-GPU code path - RCCL init, bucketed all-reduce hooks on the HIP autograd Functions - runs on one GPU")
     args = ap.parse_args()
+    if os.environ.get("HVC_FORCE_DDP") == "1":
+        args.ddp = True
     from hvc.dist_env import ensure_rccl_env
     ensure_rccl_env()          # also when an external launcher started this rank; no HIP call has been made yet
 
@@ -234,8 +239,13 @@ def main():
     single = os.environ.get("HVC_TEST_SINGLE_DEVICE") == "1"
     device = torch.device("cuda", 0 if single else local_rank)
     torch.cuda.set_device(device)
-    if world > 1:
+    distributed = world > 1 or args.ddp
+    if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:                                        # --ddp on one GPU: no launcher has set the rendezvous
+            os.environ.setdefault("MASTER_PORT", str(_free_port()))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         backend = os.environ.get("HVC_DIST_BACKEND", "nccl")
         if backend == "nccl":
             torch.distributed.init_process_group("nccl", device_id=device)   # RCCL over xGMI
@@ -246,21 +256,34 @@ def main():
     wl = WORKLOADS[args.workload]
     # hipGraph replay of the whole step where the step is launch-bound (64^3: ~300 launches in ~10 ms of kernels); the
     # 128^3 / 256^3 steps are GPU-bound and run eagerly, which also lets HIP events bracket their kernels in the timed region
-    use_graph = world == 1 and (args.graph == "on" or (args.graph == "auto" and args.workload == "direct64"))
+    # Under DDP the captured step contains the bucketed RCCL all-reduces (torch records NCCL collectives into a capture): DDP is
+    # built with static_graph=True on the stream the step is warmed up (>= 11 eager iterations: DDP's reducer rebuilds its buckets
+    # and settles its hook order over the first ones) and captured on.
+    use_graph = args.graph == "on" or (args.graph == "auto" and args.workload == "direct64")
+    if distributed and torch.distributed.get_backend() != "nccl":
+        use_graph = False                                  # rehearsal backends (gloo) cannot be captured
     model, crit, opt = build(wl, device, capturable=use_graph)
     params = [p for p in model.parameters() if p.requires_grad]
     fwd_flops, geom = fwd_flops_per_volume(model)
     step_model = model
-    if world > 1:
-        step_model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[device.index], gradient_as_bucket_view=True,
-                                                               bucket_cap_mb=32)
+    graph_stream = None
+    if distributed:
+        ddp_kw = dict(device_ids=[device.index], gradient_as_bucket_view=True, bucket_cap_mb=32, static_graph=use_graph)
+        if use_graph:       # whole-step capture: DDP constructor, warm-up and capture on ONE side stream (hvc/graph.py: GraphedStep)
+            graph_stream = torch.cuda.Stream(device=device)
+            graph_stream.wait_stream(torch.cuda.current_stream(device))
+            with torch.cuda.stream(graph_stream):
+                step_model = torch.nn.parallel.DistributedDataParallel(model, **ddp_kw)
+            torch.cuda.current_stream(device).wait_stream(graph_stream)
+        else:               # eager: on the stream the steps run on (its AccumulateGrad nodes then sit on that stream too)
+            step_model = torch.nn.parallel.DistributedDataParallel(model, **ddp_kw)
     xr, ct = make_batch(wl, rank, device)
     # identical initial weights on every rank (seed 0 in build(); DDP broadcasts rank 0's anyway), but each
     # data-parallel replica draws its own dropout seeds, as the reference's per-process generators do
     torch.manual_seed(1234 + rank)
 
     def barrier():
-        if world > 1:
+        if distributed:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -269,7 +292,8 @@ def main():
     step = eager_step
     if use_graph:
         from hvc.graph import GraphedStep
-        graphed = GraphedStep(lambda a_, b_: train_step(step_model, params, crit, opt, a_, b_), [xr, ct], warmup=max(args.warmup, 3))
+        graphed = GraphedStep(lambda a_, b_: train_step(step_model, params, crit, opt, a_, b_), [xr, ct],
+                              warmup=max(args.warmup, 11 if distributed else 3), stream=graph_stream)
         step = lambda: graphed(xr, ct)                    # noqa: E731
     for _ in range(args.warmup):
         step()
@@ -370,14 +394,16 @@ def main():
                                             "launches_per_step": v[2] / share_steps, "avg_launch_ms": 1e3 * v[0] / v[2]}
                                         for k, v in sorted(agg2.items())}
             out["kernel_time_share_note"] = "from an extra untimed pass with every attention / GEMM launch bracketed" if full else "timed region"
-        if world > 1:
+        if distributed:
             out["rccl_ranks"] = torch.distributed.get_world_size()
             out["dist_backend"] = torch.distributed.get_backend()
-            out["rank_ms_per_step"] = {"min": min(rank_ms), "max": max(rank_ms)}
+            out["ddp"] = {"bucket_cap_mb": 32, "gradient_as_bucket_view": True, "static_graph": bool(use_graph),
+                          "captured_in_hipgraph": bool(use_graph)}
+            if rank_ms is not None:
+                out["rank_ms_per_step"] = {"min": min(rank_ms), "max": max(rank_ms)}
             out["ipc_env"] = {"HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")}
-            # scaling comparator: the step runs eagerly under DDP (its bucketed all-reduce is not captured), so the N = 1 point of
-            # a scaling curve for this workload is the eager one
-            out["n1_comparator"] = f"python bench.py --workload {args.workload} --graph off"
+            # scaling comparator: the N = 1 point of a scaling curve is this same command with --gpus 1 (same launch mode)
+            out["n1_comparator"] = f"python bench.py --workload {args.workload} --graph {args.graph}"
             try:
                 out["nccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
             except Exception:       # noqa: BLE001 - informational only
@@ -387,7 +413,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:      # host-CPU baseline: rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if distributed:
         torch.distributed.destroy_process_group()
 
 

@@ -18,7 +18,12 @@ class GraphedStep:
     created with capturable=True.  It returns a tensor or a tuple / dict of tensors (e.g. the loss), which stay valid until the
     next call."""
 
-    def __init__(self, step_fn, example_inputs, warmup=3):
+    def __init__(self, step_fn, example_inputs, warmup=3, stream=None):
+        """stream: the side stream to warm up AND capture on (default: a fresh one).  Under DistributedDataParallel pass the stream
+        the DDP wrapper was constructed on: DDP hooks into AccumulateGrad nodes that live on its constructor's stream, and a
+        capture taken on any other stream replays wrongly on ROCm 7 (measured, scripts/ddp_graph_probe2.py: every gradient
+        non-finite after the first replay, although the eager steps on that stream pair are fine) - with constructor, warm-up
+        and capture on ONE stream the captured DDP step, RCCL all-reduce included, replays bit for bit like the plain one."""
         if not torch.cuda.is_available():
             raise RuntimeError("GraphedStep needs the MI355X HIP device")
         if warmup < 1:
@@ -31,7 +36,7 @@ class GraphedStep:
         dev = self.static_inputs[0].device
         self.counter = torch.zeros(1, dtype=torch.int32, device=dev)          # read as uint32 on the device
         _lib.check(self.lib.hvc_set_seed_counter(self.counter.data_ptr()), "hvc_set_seed_counter")
-        side = torch.cuda.Stream(device=dev)
+        side = stream if stream is not None else torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
             for _ in range(warmup):
@@ -40,8 +45,8 @@ class GraphedStep:
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self._advance(torch.cuda.current_stream(dev))
+        with torch.cuda.graph(self.graph, stream=side):
+            self._advance(side)
             self.static_outputs = step_fn(*self.static_inputs)
         # The graph has baked in the addresses of the cached compute-dtype / conv-layout weight copies (hvc.functional): hold
         # them, and refuse to replay once a parameter's copy has been rebuilt elsewhere (invalidate_param_casts, a
