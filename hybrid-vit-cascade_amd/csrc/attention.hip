@@ -86,6 +86,13 @@ __device__ __forceinline__ void lds_dma16(const void* src, const bf16* dst) {
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(src), "s"(lds_addr) : "memory");
 }
+// The same piece with a wave-uniform 64-bit base (SGPR pair) and a 32-bit per-lane byte offset: no 64-bit vector address arithmetic.
+__device__ __forceinline__ void lds_dma16_s(const void* sbase, uint32_t voff, const bf16* dst) {
+    const uint32_t lds_addr = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)dst);
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
+}
 template <typename T, int D, bool VEC>
 struct TileLoader {
     static constexpr int NS = NSplit<T>::value;
@@ -721,6 +728,418 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void attn_fwd2_kern
 }
 
 // ---------------------------------------------------------------------------------
+// forward, software-pipelined (round 4; bf16, 16-byte addressable operands, LDS-DMA tiles)
+// ---------------------------------------------------------------------------------
+// Same arithmetic as attn_fwd_kernel (32 query rows per wavefront, 64-key tiles, S^T = K Q^T with the query on the lane, the same
+// dropout lots), but the tile loop is skewed by one tile so that every stretch of the steady state carries matrix AND vector
+// work that do not depend on each other - an in-order wavefront can then issue its exponentials / hashes / converts in the
+// shadow of its own MFMAs instead of running them phase after phase (the phase-separated kernels above overlap matrix and vector
+// work only between the two wavefronts of a SIMD, which one barrier per tile keeps in the SAME phase; rocprofv3 of round 3: matrix
+// pipe 41 % busy, vector issue 48 %, 63 % of the wave-cycles waiting):
+//   block 1 of iteration t :  S(t+1) = K(t+1) Q^T - m   (8 MFMA + 8 K row-fragment reads)   ||  p = exp2(S(t)), row sums (64 VALU)
+//   block 2 of iteration t :  O += V(t)^T P(t)^T        (8 MFMA + 16 transposed V reads)    ||  convert + keep-mask hash of the next
+//                             16-key group of P(t) (the hash is independent of any data)
+// There is NO branch in the steady state.  The reference exponent m of a row is fixed by tile 0 (every row adopts that tile's
+// maximum) and is never moved afterwards: probabilities are kept as exp2(s - m) in fp32 / bf16, whose exponent range (2^127) -
+// not the 2^6 head-room of the kernels above - is the only limit, and the relative precision of P, of the row sum and of O does not
+// depend on the common factor 2^(max - m) (it cancels in O = sum P V / sum P; LSE = m + log2 sum P).  A row whose later scores
+// exceed tile 0's maximum by more than ~2^64 (44 nats: never seen outside adversarial tests) shows in its row sum (> 2^80, inf or
+// NaN); its wavefront then recomputes its 32 rows after the sweep with the classic online softmax straight from global
+// memory (slow_rows below: same MFMA fragments, no LDS, no barriers - correct, 3-5x slower, exercised by the spike tests).
+// (A rescale path that rejoins the loop cost ~95 register copies per tile on the COMMON path - hipcc places the copies of the
+// join there - or, under __builtin_expect, had the block outlined as a cold function with the whole loop state in scratch.)
+// K and V are kept four tiles deep in LDS each (read / landed / in flight / free), fetched by LDS-DMA TWO tiles ahead of their
+// readers from a wave-uniform base + 32-bit offsets behind a COUNTED vmcnt (the newest requests stay in flight across the one
+// barrier per tile: a request has two iterations, ~1 us, to land - with one iteration every tile ended waiting for it).
+constexpr int kKBufs = 4;
+constexpr float kOverflowSum = 1.2089258e24f;      // 2^80: a row's probabilities sum to less (so |O| <= 2^80 max|v| stays finite), or the row is redone carefully
+template <int D, bool DROP, int WAVES>
+__global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void attn_fwdp_kernel(const AttnArgs a_in) {
+    using T = bf16;
+    constexpr int THREADS = 64 * WAVES, QBW = 32 * WAVES;
+    constexpr int TILE = kKT * D;                      // elements per tile image
+    constexpr int CPR = D / 8, CH = kKT * CPR;         // 16-byte chunks per tile row / per tile
+    constexpr bool SPLIT = 2 * CH == THREADS;          // half of the workgroup fetches K, the other half V (one chunk per thread)
+    constexpr int NCH = SPLIT ? 1 : CH / THREADS;      // chunks per thread and operand otherwise
+    static_assert(SPLIT || (CH % THREADS == 0 && NCH >= 1), "tile chunks must divide over the workgroup");
+    AttnArgs a = a_in;
+    a.seed_lo = seed_with_counter(a_in.seed_lo, a_in.seed_ctr);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16* lds = reinterpret_cast<bf16*>(smem);         // [4 K tiles][4 V tiles]
+    constexpr int VBASE = kKBufs * TILE;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+
+    const int nqb = (a.Nq + QBW - 1) / QBW;
+    int bh, qb;
+    block_map(blockIdx.x, a.B * a.H, nqb, bh, qb);
+    const int b = bh / a.H, hh = bh % a.H;
+    const T* qp = reinterpret_cast<const T*>(a.q) + b * a.q_sb + hh * a.q_sh;
+    const T* kp = reinterpret_cast<const T*>(a.k) + b * a.k_sb + hh * a.k_sh;
+    const T* vp = reinterpret_cast<const T*>(a.v) + b * a.v_sb + hh * a.v_sh;
+    T* op = reinterpret_cast<T*>(a.o) + b * a.o_sb + hh * a.o_sh;
+
+    const int qrow = qb * QBW + wave * 32 + r;
+    const bool qvalid = qrow < a.Nq;
+    const int qrow_c = qvalid ? qrow : a.Nq - 1;
+    const float sl2 = a.scale * kLog2e;
+    bf16x8 qf[1][D / 16];
+    load_row_frags_scaled<T, 1, D / 16, true>(qp + (int64_t)qrow_c * a.q_sn, h, true, sl2, qf);
+    const uint32_t rowkey = DROP ? drop_rowkey(a, bh, qrow_c) ^ (h ? kGrpH : 0u) : 0u;
+    const uint32_t tm1x2 = DROP ? ((uint32_t)(drop_ts(a) - 1) & 0xffffu) * 0x10001u : 0u;
+
+    // tile loader: thread -> chunk ltid (+ THREADS i) of its operand's tile; the image is lane-linear, the XOR swizzle is applied
+    // to the SOURCE chunk (see TileLoader).  Addresses are a wave-uniform base (K / V of this (b, h)) plus a 32-bit byte offset
+    // (the launcher checks that a (b, h) slice spans < 2^31 bytes); rows past the end of K / V are clamped to the last row
+    // (finite values, zero weight) by clamping the row's byte offset.
+    const int ltid = SPLIT ? tid % CH : tid;
+    const bool isv = SPLIT && tid >= CH;
+    const int lrow = ltid / CPR;
+    const uint32_t lch8 = (uint32_t)(tile_off<D>(lrow, ltid % CPR) - lrow * D) * 2u;     // byte offset of the logical chunk in its row
+    const int dwave = __builtin_amdgcn_readfirstlane((ltid >> 6) * 64 * 8);
+    const uint32_t k_rowb = (uint32_t)a.k_sn * 2u, v_rowb = (uint32_t)a.v_sn * 2u;      // bytes per row
+    const uint32_t k_last = (uint32_t)(a.Nk - 1) * k_rowb, v_last = (uint32_t)(a.Nk - 1) * v_rowb;
+    uint32_t k_roff[NCH], v_roff[NCH];                                                   // byte offsets of this thread's rows in tile 0
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        k_roff[i] = (uint32_t)(lrow + i * (THREADS / CPR)) * k_rowb;
+        v_roff[i] = (uint32_t)(lrow + i * (THREADS / CPR)) * v_rowb;
+    }
+    auto dma_k = [&](int tile, bf16* image) {
+        const uint32_t toff = (uint32_t)tile * (uint32_t)kKT * k_rowb;                  // wave-uniform
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) lds_dma16_s(kp, min(k_roff[i] + toff, k_last) + lch8, image + (i * THREADS * 8 + dwave));
+    };
+    auto dma_v = [&](int tile, bf16* image) {
+        const uint32_t toff = (uint32_t)tile * (uint32_t)kKT * v_rowb;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) lds_dma16_s(vp, min(v_roff[i] + toff, v_last) + lch8, image + (i * THREADS * 8 + dwave));
+    };
+    auto fetch = [&](int kt_tile, bf16* kimage, int vt_tile, bf16* vimage) {      // K tile kt_tile and V tile vt_tile
+        if constexpr (SPLIT) {
+            if (isv) dma_v(vt_tile, vimage);
+            else dma_k(kt_tile, kimage);
+        } else {
+            dma_k(kt_tile, kimage);
+            dma_v(vt_tile, vimage);
+        }
+    };
+    // every DMA but the pieces this thread issued in the CURRENT iteration has landed (vmcnt counts in issue order): the tiles the
+    // next iteration reads were requested a whole iteration earlier, the newest requests stay in flight across the barrier
+    constexpr int INFLIGHT = SPLIT ? 1 : 2 * NCH;
+    auto dma_wait_prev = [] { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFLIGHT) : "memory"); };
+    auto dma_wait_all = [] { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+
+    const bf16* kaddr[D / 16];
+    const bf16* vaddr[D / 32][2];
+#pragma unroll
+    for (int s = 0; s < D / 16; ++s) kaddr[s] = lds + row_frag_lane_off<D>(16 * s, lane);
+#pragma unroll
+    for (int dt = 0; dt < D / 32; ++dt) {
+        int oa, ob;
+        tr_frag_lane_off<D, true>(32 * dt, lane, oa, ob);
+        vaddr[dt][0] = lds + oa;
+        vaddr[dt][1] = lds + ob;
+    }
+
+    const int nt = (a.Nk + kKT - 1) / kKT;
+    // prologue: K(0), K(1), K(2), V(0), V(1)
+    if constexpr (SPLIT) {
+        if (isv) { dma_v(0, lds + VBASE); dma_v(1, lds + VBASE + TILE); }
+        else { dma_k(0, lds); dma_k(1, lds + TILE); dma_k(2, lds + 2 * TILE); }
+    } else {
+        dma_k(0, lds);
+        dma_k(1, lds + TILE);
+        dma_k(2, lds + 2 * TILE);
+        dma_v(0, lds + VBASE);
+        dma_v(1, lds + VBASE + TILE);
+    }
+    dma_wait_all();
+    __syncthreads();
+
+    f32x16 negm, o[D / 32];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) negm[i] = 0.f;
+#pragma unroll
+    for (int dt = 0; dt < D / 32; ++dt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[dt][i] = 0.f;
+    float l = 0.f;
+    // (Row sums through a ones-operand MFMA - 4 more MFMAs per tile instead of 32 vector adds - measured 2 % SLOWER: matrix time is
+    // not free under the vector stream here; profiles/r04_attention_pipelined_forward.txt.)
+
+    auto mask_tail = [&](f32x16 (&st)[2], int t) {
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                if (t * kKT + 32 * kt + acc_row(i, h) >= a.Nk) st[kt][i] = -INFINITY;
+    };
+    auto row_max = [&](const f32x16 (&st)[2]) {
+        float m = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) m = fmaxf(m, st[kt][i]);
+        return fmaxf(m, __shfl_xor(m, 32, 64));
+    };
+    // p = exp2(s) for elements [e0, e0 + n) of the tile (element = 16 kt + i), in place, summed into two plain add chains that are
+    // opaque to the SLP vectoriser (see attn_fwd2_kernel); a tile's chains are folded into l by close_sums()
+    float acc0 = 0.f, acc1 = 0.f;
+    auto exps = [&](f32x16 (&st)[2], int e0, int n) {
+#pragma unroll
+        for (int e = e0; e < e0 + n; e += 2) {
+            const int kt = e >> 4, i = e & 15;
+            const float p0 = __builtin_amdgcn_exp2f(st[kt][i]), p1 = __builtin_amdgcn_exp2f(st[kt][i + 1]);
+            acc0 += p0;
+            asm("" : "+v"(acc0));
+            acc1 += p1;
+            asm("" : "+v"(acc1));
+            st[kt][i] = p0;
+            st[kt][i + 1] = p1;
+        }
+    };
+    auto close_sums = [&] {
+        l += acc0 + acc1;
+        acc0 = 0.f;
+        acc1 = 0.f;
+    };
+    // O^T += V^T P^T for the probabilities in st of tile `tile`, V image at element offset voff: per 16-key group g = 2 kt + s2 the
+    // probabilities are converted to bf16 and masked (keep masks hashed right here: independent of any data) and the transposed V
+    // fragments requested while the MFMAs of the group before run; the fences keep hipcc from hoisting every LDS read to the top
+    // (it then spilt the Q fragments into scratch inside the loop) and from clustering the MFMAs at the end.
+    auto pv = [&](const f32x16 (&st)[2], int tile, int voff) {
+        const uint32_t rk_tile = rowkey + (uint32_t)tile * kTileAdd;
+        auto prep = [&](int g, bf16x8& pf, bf16x8 (&vf)[D / 32]) {
+            const int kt = g >> 1, s2 = g & 1;
+            float x[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[j] = st[kt][8 * s2 + j];
+            bf16x8 im[1];
+            acc_split<1>(x, im);
+            if constexpr (DROP) {
+                u32x4 w = __builtin_bit_cast(u32x4, im[0]);
+#pragma unroll
+                for (int g2 = 0; g2 < 2; ++g2) {      // group j = 8 kt + 2 (2 s2 + g2) + h of the tile
+                    const uint32_t m = rk_tile ^ (drop_grp_a(kt) ^ drop_grp_b(2 * s2 + g2));
+                    uint32_t la, lb;
+                    drop_lots4(m, la, lb);
+                    w[2 * g2] &= drop_keepmask2(la, tm1x2);
+                    w[2 * g2 + 1] &= drop_keepmask2(lb, tm1x2);
+                }
+                im[0] = __builtin_bit_cast(bf16x8, w);
+            }
+            pf = im[0];
+#pragma unroll
+            for (int dt = 0; dt < D / 32; ++dt) {
+                const int VO = voff + (32 * kt + 16 * s2) * D;
+                vf[dt] = tr_frag_at(vaddr[dt][0] + VO, vaddr[dt][1] + VO);
+            }
+        };
+        bf16x8 pf, pn, vf[D / 32], vn[D / 32];
+        prep(0, pf, vf);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+#pragma unroll
+            for (int dt = 0; dt < D / 32; ++dt) o[dt] = mfma32(vf[dt], pf, o[dt]);
+            if (g + 1 < 4) prep(g + 1, pn, vn);
+            pf = pn;
+#pragma unroll
+            for (int dt = 0; dt < D / 32; ++dt) vf[dt] = vn[dt];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    // tile 0: its scores and the reference (every row adopts this tile's maximum, for the whole sweep)
+    f32x16 sc[2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+        sc[kt] = negm;
+#pragma unroll
+        for (int s = 0; s < D / 16; ++s)
+            sc[kt] = mfma32(*reinterpret_cast<const bf16x8*>(kaddr[s] + 32 * kt * D), qf[0][s], sc[kt]);
+    }
+    if (a.Nk < kKT) mask_tail(sc, 0);
+    {
+        const float m0 = row_max(sc);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) negm[i] = -m0;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sc[kt][i] -= m0;
+    }
+
+    // steady state, tile t (T4 = t & 3 selects the buffers at compile time); tile t+1 exists
+    auto body = [&](auto t4_tag, int t) {
+        constexpr int T4 = decltype(t4_tag)::value;
+        constexpr int KR = ((T4 + 1) & 3) * TILE, KD = ((T4 + 3) & 3) * TILE;
+        constexpr int VR = VBASE + T4 * TILE, VD = VBASE + ((T4 + 2) & 3) * TILE;
+        fetch(t + 3, lds + KD, t + 2, lds + VD);         // two tiles ahead of their readers
+        // block 1: S(t+1) = K(t+1) Q^T - m, one 16-wide d step (2 MFMAs) at a time, each with its share of tile t's exponentials
+        // behind it and the next step's two K fragments requested ahead
+        f32x16 sn[2];
+        bf16x8 kf[2], kn[2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) kf[kt] = *reinterpret_cast<const bf16x8*>(kaddr[0] + (KR + 32 * kt * D));
+#pragma unroll
+        for (int s = 0; s < D / 16; ++s) {
+            if (s + 1 < D / 16) {
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt) kn[kt] = *reinterpret_cast<const bf16x8*>(kaddr[s + 1] + (KR + 32 * kt * D));
+            }
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) sn[kt] = mfma32(kf[kt], qf[0][s], s == 0 ? negm : sn[kt]);
+            constexpr int EPS = 32 / (D / 16);            // exponentials per d step (8 at d = 64, 16 at d = 32)
+            exps(sc, s * EPS, EPS);
+            kf[0] = kn[0];
+            kf[1] = kn[1];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        close_sums();
+        pv(sc, t, VR);                                    // block 2
+        sc[0] = sn[0];
+        sc[1] = sn[1];
+        dma_wait_prev();
+        __syncthreads();
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    using I3 = std::integral_constant<int, 3>;
+    int t = 0;
+    for (; t + 4 < nt; t += 4) {
+        body(I0{}, t);
+        body(I1{}, t + 1);
+        body(I2{}, t + 2);
+        body(I3{}, t + 3);
+    }
+    if (t + 1 < nt) {
+        body(I0{}, t);
+        ++t;
+        if (t + 1 < nt) {
+            body(I1{}, t);
+            ++t;
+            if (t + 1 < nt) {
+                body(I2{}, t);
+                ++t;
+            }
+        }
+    }
+    // last tile (t = nt - 1): nothing to prefetch, ragged tail masked
+    if (a.Nk % kKT) mask_tail(sc, t);
+    exps(sc, 0, 32);
+    close_sums();
+    pv(sc, t, VBASE + (t & 3) * TILE);
+    dma_wait_all();                                       // the (clamped, unused) requests of the last iterations: nothing in flight at exit
+
+    if (__any(!(l <= kOverflowSum))) {
+        // Some row of this wavefront outgrew tile 0's reference by more than the fp32 exponent range allows (or produced a NaN):
+        // its 32 rows again, carefully - classic online softmax with the reference moved BEFORE the exponentials (as in
+        // attn_fwd_kernel), operands straight from global memory in fragment layout (K rows: one 16-byte load per lane; V^T:
+        // eight 2-byte loads per fragment), no LDS (other wavefronts may still be reading the last tiles), no barriers.
+#pragma unroll
+        for (int i = 0; i < 16; ++i) negm[i] = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < D / 32; ++dt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) o[dt][i] = 0.f;
+        l = 0.f;
+        for (int ts = 0; ts < nt; ++ts) {
+            f32x16 st[2];
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+                st[kt] = negm;
+                const int key = min(ts * kKT + 32 * kt + r, a.Nk - 1);
+#pragma unroll
+                for (int s = 0; s < D / 16; ++s) {
+                    const bf16x8 kfr = *reinterpret_cast<const bf16x8*>(kp + (int64_t)key * a.k_sn + 16 * s + 8 * h);
+                    st[kt] = mfma32(kfr, qf[0][s], st[kt]);
+                }
+            }
+            if ((ts + 1) * kKT > a.Nk) mask_tail(st, ts);
+            const float mloc = row_max(st);
+            if (ts == 0 || __any(mloc > kRescaleLog2)) {
+                const float shift = ts == 0 ? mloc : fmaxf(mloc, 0.f);
+                const float alpha = ts == 0 ? 1.f : __builtin_amdgcn_exp2f(-shift);
+                l *= alpha;
+#pragma unroll
+                for (int dt = 0; dt < D / 32; ++dt)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) o[dt][i] *= alpha;
+                const float nm = negm[0] - shift;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) negm[i] = nm;
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) st[kt][i] -= shift;
+            }
+            float rs = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    st[kt][i] = __builtin_amdgcn_exp2f(st[kt][i]);
+                    rs += st[kt][i];
+                }
+            l += rs;
+            const uint32_t rk_tile = rowkey + (uint32_t)ts * kTileAdd;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    float x[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) x[j] = st[kt][8 * s2 + j];
+                    bf16x8 im[1];
+                    acc_split<1>(x, im);
+                    if constexpr (DROP) {
+                        u32x4 w = __builtin_bit_cast(u32x4, im[0]);
+#pragma unroll
+                        for (int g2 = 0; g2 < 2; ++g2) {
+                            const uint32_t m = rk_tile ^ (drop_grp_a(kt) ^ drop_grp_b(2 * s2 + g2));
+                            uint32_t la, lb;
+                            drop_lots4(m, la, lb);
+                            w[2 * g2] &= drop_keepmask2(la, tm1x2);
+                            w[2 * g2 + 1] &= drop_keepmask2(lb, tm1x2);
+                        }
+                        im[0] = __builtin_bit_cast(bf16x8, w);
+                    }
+                    const int k0 = ts * kKT + 32 * kt + 16 * s2;      // V^T fragment: rows k0 + 4h + j and k0 + 8 + 4h + j, column 32 dt + r
+#pragma unroll
+                    for (int dt = 0; dt < D / 32; ++dt) {
+                        bf16x8 vfr;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const int key = min(k0 + 4 * h + (j & 3) + 8 * (j >> 2), a.Nk - 1);
+                            vfr[j] = vp[(int64_t)key * a.v_sn + 32 * dt + r];
+                        }
+                        o[dt] = mfma32(vfr, im[0], o[dt]);
+                    }
+                }
+        }
+    }
+
+    const float ltot = l + __shfl_xor(l, 32, 64);
+    const float inv = (DROP ? a.keep_scale : 1.f) / ltot;
+    if (qvalid) {
+        T* orow = op + (int64_t)qrow * a.o_sn;
+#pragma unroll
+        for (int dt = 0; dt < D / 32; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                bf16x4 w;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) w[j] = f2bf(o[dt][4 * g + j] * inv);
+                *reinterpret_cast<bf16x4*>(orow + 32 * dt + 8 * g + 4 * h) = w;
+            }
+        if (h == 0) a.lse[(int64_t)bh * a.Nq + qrow] = (__builtin_amdgcn_logf(ltot) - negm[0]) * kLn2;
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // backward: delta[bh][q] = sum_d dO * O
 // ---------------------------------------------------------------------------------
 template <typename T, int D>
@@ -1264,6 +1683,32 @@ size_t extra_lds() {
 
 template <typename T, int D, bool DROP, bool VEC>
 hipError_t launch_fwd(const AttnArgs& a, hipStream_t st) {
+    if constexpr (sizeof(T) == 2 && VEC && HVC_ATTN_DMA) {
+        // software-pipelined kernel (256-row workgroups of eight wavefronts, one per CU) once they fill every CU twice over;
+        // HVC_ATTN_PIPE=0 keeps the phase-separated kernels, =2 takes the pipelined one on any grid (tests); a row pin (below) wins
+        const int pipe = option(kOptAttnPipe);
+        const int64_t nwgp = (int64_t)((a.Nq + 255) / 256) * a.B * a.H;
+        // its tile loader addresses K / V rows of one (b, h) by 32-bit byte offsets from a wave-uniform base
+        const bool span_ok = ((int64_t)(a.Nk - 1) * a.k_sn + D) * 2 < (int64_t(1) << 31) && ((int64_t)(a.Nk - 1) * a.v_sn + D) * 2 < (int64_t(1) << 31);
+        if (option(kOptAttnFwdRows) == 0 && span_ok && (pipe == 2 || (pipe == 1 && nwgp >= 512))) {
+            const size_t ldsp = (size_t)(kKBufs + 4) * kKT * D * sizeof(bf16) + extra_lds();
+            // d = 32: 128-row workgroups of four wavefronts, two or three per CU (measured -6 % against the 8-wavefront form there:
+            // half the vector work per MFMA hides under fewer co-resident barriers); d = 64: eight wavefronts.  HVC_ATTN_FWD_WAVES pins.
+            const int wpin = option(kOptAttnFwdWaves);
+            if (wpin == 4 || (wpin != 8 && D == 32)) {
+                auto kp4 = attn_fwdp_kernel<D, DROP, 4>;
+                hipError_t e4 = set_lds(kp4, ldsp);
+                if (e4 != hipSuccess) return e4;
+                hipLaunchKernelGGL(kp4, dim3((unsigned)(((a.Nq + 127) / 128) * a.B * a.H)), dim3(256), ldsp, st, a);
+                return hipGetLastError();
+            }
+            auto kp8 = attn_fwdp_kernel<D, DROP, 8>;
+            hipError_t ep = set_lds(kp8, ldsp);
+            if (ep != hipSuccess) return ep;
+            hipLaunchKernelGGL(kp8, dim3((unsigned)nwgp), dim3(512), ldsp, st, a);
+            return hipGetLastError();
+        }
+    }
     if constexpr (sizeof(T) == 2 && VEC) {
         // 64 rows per wavefront once its 256-row workgroups fill every CU twice over; smaller problems keep the 128-row
         // workgroups (more of them, three per CU)

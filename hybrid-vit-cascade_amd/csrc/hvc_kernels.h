@@ -15,7 +15,7 @@ enum Option {
     kOptAttnFwdWaves,        // HVC_ATTN_FWD_WAVES    0 = by size, 4 / 8 pin the 64-row forward's workgroup form
     kOptAttnBwdWaves,        // HVC_ATTN_BWD_WAVES    0 = by size, 4 / 8 pin the dQ and dK/dV workgroup form
     kOptAttnExtraLds,        // HVC_ATTN_EXTRA_LDS    bytes added to every attention launch's LDS request (occupancy experiments)
-    kOptAttnFwdAsm,          // HVC_ATTN_FWD_ASM      1 = hand-placed steady-state forward where its shape conditions hold (default), 0 = C++ twin
+    kOptAttnPipe,            // HVC_ATTN_PIPE         1 = software-pipelined attention kernels where their shape conditions hold (default), 0 = the phase-separated twins, 2 = pipelined whenever legal (tests: small grids too)
     kOptGemmPersistent,      // HVC_GEMM_PERSISTENT   1 = persistent token-matrix GEMMs (default), 0 = one tile per workgroup
     kOptGemmStagger,         // HVC_GEMM_STAGGER      start-up stagger of the second workgroup of a CU (>= 0)
     kOptGemmHalfTile,        // HVC_GEMM_HALF_TILE    1 = 64 x 128 tiles on shapes that under-fill the chip (default)

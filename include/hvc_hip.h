@@ -56,7 +56,7 @@ int hvc_clear_seed_counter_if(const uint32_t* device_counter);
 /* Run-time switches of the library (kernel-form pins for A/B timing and for parity tests that must reach every shipped
  * instantiation of a kernel; no reference counterpart - the reference has one code path per op).  Names are those of the
  * environment variables that give the initial values when the library is loaded: HVC_ATTN_FWD_ROWS (0 | 32 | 64),
- * HVC_ATTN_FWD_WAVES (0 | 4 | 8), HVC_ATTN_BWD_WAVES (0 | 4 | 8), HVC_ATTN_FWD_ASM (1 | 0), HVC_ATTN_EXTRA_LDS (bytes),
+ * HVC_ATTN_FWD_WAVES (0 | 4 | 8), HVC_ATTN_BWD_WAVES (0 | 4 | 8), HVC_ATTN_PIPE (1 | 0 | 2), HVC_ATTN_EXTRA_LDS (bytes),
  * HVC_GEMM_PERSISTENT (1 | 0), HVC_GEMM_STAGGER (>= 0), HVC_GEMM_HALF_TILE (1 | 0), HVC_FP8_MX (0 | 1),
  * HVC_CONV_FORCE_ADDR64 (0 | 1).  Values are atomic ints read at launch time, safe to set from any thread between launches;
  * unknown names and negative values return HVC_E_BADARG. */

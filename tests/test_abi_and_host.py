@@ -370,7 +370,7 @@ def test_options_are_declared_in_the_header_and_bound():
     from hvc import _lib, ops
     lib = _lib.load()
     hdr = open(os.path.join(ROOT, "include", "hvc_hip.h")).read()
-    for name in ("HVC_ATTN_FWD_ROWS", "HVC_ATTN_FWD_WAVES", "HVC_ATTN_BWD_WAVES", "HVC_ATTN_FWD_ASM", "HVC_GEMM_PERSISTENT",
+    for name in ("HVC_ATTN_FWD_ROWS", "HVC_ATTN_FWD_WAVES", "HVC_ATTN_BWD_WAVES", "HVC_ATTN_PIPE", "HVC_GEMM_PERSISTENT",
                  "HVC_GEMM_STAGGER", "HVC_GEMM_HALF_TILE", "HVC_FP8_MX", "HVC_CONV_FORCE_ADDR64", "HVC_ATTN_EXTRA_LDS"):
         assert name in hdr, name
         old = ops.get_option(name)

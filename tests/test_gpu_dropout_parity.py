@@ -68,8 +68,17 @@ def _unaligned(t):
     return buf[..., 1:]
 
 
-# (B, H, Nq, Nk, D, dtype, fwd rows, fwd waves, bwd waves, p, unaligned)
+# (B, H, Nq, Nk, D, dtype, fwd rows, fwd waves, bwd waves, p, unaligned); fwd rows "pipe" = the software-pipelined forward
+# (attn_fwdp_kernel, HVC_ATTN_PIPE=2: taken on any grid), Nk chosen to hit every remainder of its four-tile unrolled sweep
 CASES = {
+    "pipe_bf16_d64_1tile_ragged":  (1, 2, 300, 50, 64, torch.bfloat16, "pipe", 0, 4, 0.1, False),
+    "pipe_bf16_d64_2tiles":        (2, 2, 260, 128, 64, torch.bfloat16, "pipe", 0, 4, 0.1, False),
+    "pipe_bf16_d64_3tiles_ragged": (1, 3, 515, 190, 64, torch.bfloat16, "pipe", 0, 4, 0.1, False),
+    "pipe_bf16_d64_4tiles":        (1, 2, 256, 256, 64, torch.bfloat16, "pipe", 0, 8, 0.1, False),
+    "pipe_bf16_d64_5tiles_ragged": (2, 2, 700, 300, 64, torch.bfloat16, "pipe", 0, 8, 0.1, False),
+    "pipe_bf16_d64_11tiles":       (1, 4, 1000, 700, 64, torch.bfloat16, "pipe", 0, 8, 0.25, False),
+    "pipe_bf16_d32_7tiles_ragged": (1, 8, 530, 401, 32, torch.bfloat16, "pipe", 0, 8, 0.1, False),
+    "pipe_bf16_d32_16tiles":       (2, 2, 300, 1024, 32, torch.bfloat16, "pipe", 0, 4, 0.1, False),
     "fwd32_f32_d32_ragged":        (2, 2, 193, 131, 32, torch.float32, 32, 0, 4, 0.1, False),
     "fwd32_f32_d64_ragged":        (1, 3, 130, 257, 64, torch.float32, 32, 0, 4, 0.1, False),
     "fwd32_f32_d64_scalar_loads":  (1, 2, 97, 70, 64, torch.float32, 32, 0, 4, 0.25, True),
@@ -94,7 +103,12 @@ def test_attention_dropout_on_vs_masked_fp64_oracle(case, hvc_option):
     from oracle import hvc_oracle as O
     B, H, Nq, Nk, D, dtype, rows, fwaves, bwaves, p, unaligned = CASES[case]
     bf16 = dtype == torch.bfloat16
-    hvc_option("HVC_ATTN_FWD_ROWS", rows)
+    if rows == "pipe":
+        hvc_option("HVC_ATTN_FWD_ROWS", 0)
+        hvc_option("HVC_ATTN_PIPE", 2)
+    else:
+        hvc_option("HVC_ATTN_FWD_ROWS", rows)
+        hvc_option("HVC_ATTN_PIPE", 0)
     hvc_option("HVC_ATTN_FWD_WAVES", fwaves)
     hvc_option("HVC_ATTN_BWD_WAVES", bwaves)
     if case.startswith("cross_qsplit"):      # few key blocks: dK / dV come from query-range slices summed in a second pass
@@ -157,7 +171,7 @@ def _block_seeds(torch_seed):
 
 
 @pytest.mark.parametrize("mode", ["f32", "bf16"])
-@pytest.mark.parametrize("cfg", ["golden_d32", "d64_pinned_large_forms"])
+@pytest.mark.parametrize("cfg", ["golden_d32", "d64_pinned_large_forms", "d64_phase_separated_64row"])
 def test_block_train_mode_dropout_on_vs_masked_oracle(golden, mode, cfg, hvc_option):
     """HybridViTBlock3D in TRAIN mode, p = 0.1 on all six dropouts (models/hybrid_vit_backbone.py:38, :77, :79, :117-139): the six
     masks the HIP chain drew are recovered (attention masks by one-hot V under the block's own seeds, GEMM-epilogue masks from
@@ -181,8 +195,12 @@ def test_block_train_mode_dropout_on_vs_masked_oracle(golden, mode, cfg, hvc_opt
             blk.adaln.linear.weight.copy_(torch.randn(blk.adaln.linear.weight.shape, generator=gg) * 0.05)
             blk.adaln.linear.bias.copy_(torch.randn(blk.adaln.linear.bias.shape, generator=gg) * 0.5)
         x, ctx, cond, w = (torch.randn(*s, generator=gg) for s in ((B, N, Cn), (B, M, Cc), (B, cond_dim), (B, N, Cn)))
-        hvc_option("HVC_ATTN_FWD_ROWS", 64)       # the forms the 128^3 benchmark runs: 64-row forward, 8-wavefront workgroups
-        hvc_option("HVC_ATTN_FWD_WAVES", 8)
+        if cfg == "d64_phase_separated_64row":
+            hvc_option("HVC_ATTN_PIPE", 0)
+            hvc_option("HVC_ATTN_FWD_ROWS", 64)
+            hvc_option("HVC_ATTN_FWD_WAVES", 8)
+        else:
+            hvc_option("HVC_ATTN_PIPE", 2)        # the forms the 128^3 benchmark runs: pipelined forward, 8-wavefront backward workgroups
         hvc_option("HVC_ATTN_BWD_WAVES", 8)
     D = Cn // heads
     bf16 = mode == "bf16"
@@ -220,3 +238,43 @@ def test_block_train_mode_dropout_on_vs_masked_oracle(golden, mode, cfg, hvc_opt
         e = _err(got, ref, bf16)
         _note(f"{cfg}/{name}", e, tol, metric)
         assert e <= tol, (cfg, mode, name, e)
+
+
+@pytest.mark.parametrize("factor", [3.0, 7.0, 30.0])
+@pytest.mark.parametrize("D", [64, 32])
+@pytest.mark.parametrize("p", [0.0, 0.1])
+def test_pipelined_forward_late_score_spikes(factor, D, p, hvc_option):
+    """The software-pipelined forward fixes a row's reference exponent at tile 0 and never moves it: a later score far above it
+    makes probabilities of up to 2^60 times the tile-0 scale (factor 3: ~2^30, the relative precision of P, of the row sum and of O
+    must not suffer), and past the fp32 range the wavefront must notice (sticky maximum of the tile sums) and redo its rows with
+    the classic online softmax (factors 7 and 30: ~2^77 and overflow to inf).  O and LSE against the fp64 oracle (with the
+    kernel's own keep mask when dropout is on); the spiked rows and their plain neighbours are both checked."""
+    from hvc import ops
+    from oracle import hvc_oracle as O
+    B, H, Nq, Nk = 1, 2, 300, 450
+    hvc_option("HVC_ATTN_PIPE", 2)
+    g = torch.Generator().manual_seed(int(factor) * 100 + D)
+    q, k, v = (torch.randn(B, n, H, D, generator=g) for n in (Nq, Nk, Nk))
+    for row, key in ((17, 200), (140, 449), (299, 70)):             # tiles 3, 7 (ragged last), 1; three different wavefronts
+        k[0, key, 0] = q[0, row, 0] * factor
+    k[0, 5, 1] = q[0, 33, 1] * factor                                # and one in tile 0 itself (adopted as the reference: no redo)
+    q, k, v = (t.to(dev(), torch.bfloat16) for t in (q, k, v))
+    seed = 99
+    keep = recover_attention_keep(B, H, Nq, Nk, D, p, seed, torch.bfloat16).cpu() if p > 0 else None
+    qr, kr, vr = (t.double().cpu().permute(0, 2, 1, 3) for t in (q, k, v))
+    ref = O.attention_core(qr, kr, vr, D ** -0.5, p_drop=p, keep=keep).permute(0, 2, 1, 3)
+    lse_ref = torch.logsumexp((qr @ kr.transpose(-2, -1)) * D ** -0.5, dim=-1)
+    o, lse = ops.attention_fwd(q, k, v, D ** -0.5, p, seed)
+    assert torch.isfinite(o.float()).all() and torch.isfinite(lse).all()
+    e = _err(o, ref, True)
+    _note(f"spike{factor}/d{D}/p{p}/o", e, BF16_TOL, "l2")
+    assert e <= BF16_TOL, e
+    rows = _err(o[0, [17, 140, 299]], ref[0, [17, 140, 299]], True)
+    assert rows <= BF16_TOL, rows
+    e = ((lse.double().cpu().view(B, H, Nq) - lse_ref).abs() / lse_ref.abs().clamp_min(1.0)).max().item()
+    _note(f"spike{factor}/d{D}/p{p}/lse", e, 2e-2, "max")
+    assert e <= 2e-2, e
+    # the phase-separated kernels (reference moved whenever a score outgrows it by 2^6) must agree with it
+    hvc_option("HVC_ATTN_PIPE", 0)
+    o2, lse2 = ops.attention_fwd(q, k, v, D ** -0.5, p, seed)
+    assert _err(o, o2, True) <= 1e-2 and (lse - lse2).abs().max().item() <= 2e-2 * max(1.0, lse2.abs().max().item())
