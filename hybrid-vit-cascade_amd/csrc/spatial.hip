@@ -288,6 +288,37 @@ __global__ __launch_bounds__(256) void axis_adjoint_kernel(const float* __restri
     }
 }
 
+// The same adjoint along a CONTIGUOUS axis (inner = 1: the W pass, which reads the whole fine gradient - 63 of every 64 bytes of
+// the resize backward at a 4x factor), fine % 4 == 0: a thread owns one coarse element and takes its candidate window as aligned
+// 16-byte loads (3 - 4 per thread; neighbouring threads' windows overlap and hit L1) instead of ~10 dependent 4-byte loads at a
+// 16-byte lane stride, which left the kernel bound by load issue at 0.14 of the HBM roof.  Same candidates, same order, same
+// weights as axis_adjoint_kernel: bit-identical sums.
+__global__ __launch_bounds__(256) void axis_adjoint_w4_kernel(const float* __restrict__ src, float* __restrict__ dst, int64_t outer, int fine,
+                                                               int coarse, int ac) {
+    const AxisMap m = axis_map(coarse, fine, ac);
+    const int64_t total = outer * coarse;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int i = (int)(idx % coarse);
+        const int64_t o = idx / coarse;
+        int lo, hi;
+        axis_range(i, m, fine, lo, hi);
+        const float* s = src + o * fine;
+        float acc = 0.f;
+        for (int c = lo & ~3; c <= hi; c += 4) {
+            const f32x4 q = *reinterpret_cast<const f32x4*>(s + c);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int f = c + j;
+                if (f >= lo && f <= hi) {
+                    const float wgt = axis_w(f, i, m, coarse);
+                    if (wgt != 0.f) acc += wgt * q[j];
+                }
+            }
+        }
+        dst[idx] = acc;
+    }
+}
+
 int grid_for(int64_t work) {
     int64_t blocks = (work + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;
@@ -344,7 +375,10 @@ hipError_t trilinear_bwd_separable_launch(const float* dout, float* dsrc, float*
     const int ac = align_corners ? 1 : 0;
     float* t1 = workspace;                                  // [B*D*H][w]
     float* t2 = workspace + (int64_t)B * D * H * w;         // [B*D][h][w]
-    hipLaunchKernelGGL(axis_adjoint_kernel, dim3(grid_for((int64_t)B * D * H * w)), dim3(256), 0, st, dout, t1, (int64_t)B * D * H, W, w, (int64_t)1, ac);
+    if ((W & 3) == 0 && (reinterpret_cast<uintptr_t>(dout) & 15u) == 0)
+        hipLaunchKernelGGL(axis_adjoint_w4_kernel, dim3(grid_for((int64_t)B * D * H * w)), dim3(256), 0, st, dout, t1, (int64_t)B * D * H, W, w, ac);
+    else
+        hipLaunchKernelGGL(axis_adjoint_kernel, dim3(grid_for((int64_t)B * D * H * w)), dim3(256), 0, st, dout, t1, (int64_t)B * D * H, W, w, (int64_t)1, ac);
     hipLaunchKernelGGL(axis_adjoint_kernel, dim3(grid_for((int64_t)B * D * h * w)), dim3(256), 0, st, t1, t2, (int64_t)B * D, H, h, (int64_t)w, ac);
     hipLaunchKernelGGL(axis_adjoint_kernel, dim3(grid_for((int64_t)B * d * h * w)), dim3(256), 0, st, t2, dsrc, (int64_t)B, D, d, (int64_t)h * w, ac);
     return hipGetLastError();

@@ -972,6 +972,28 @@ def test_drr_kernels_vs_oracle(shape):
     assert torch.allclose(lat.cpu(), v5.mean(dim=4).squeeze(1), rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(1, 256, 256, 256), (2, 96, 384, 512)])
+def test_drr_lateral_tiled_kernel_vs_oracle(shape, dtype):
+    """The ray sum along W at full size (>= 65536 rows of >= 256 voxels: drr_fwd_w_tiled_kernel - eight rows in flight per
+    wavefront, one butterfly reduction per eight rows, stores through LDS) in both output layouts: DRRRenderer's lateral view
+    (exp, clamp, transposed: diagnostic_losses.py:45-63) and DRRReprojectionLoss's mean (loss_multiscale.py:260-267), against the
+    oracle evaluated on the same (bf16-rounded) volume."""
+    from hvc import ops
+    from oracle import hvc_oracle as O
+    g = torch.Generator().manual_seed(sum(shape))
+    vol = (torch.rand(*shape, generator=g) * 2 - 1).to(dtype)
+    vd = vol.to(dev())
+    ref = O.drr_render(vol.double(), 90)                                     # (B, H, D)
+    out = ops.drr_fwd(vd, 2, exp_mode=True, mu=0.3, clamp_min=1e-6, transpose_out=True)
+    tol = 1e-5 if dtype == torch.float32 else 1e-2
+    assert out.shape == ref.shape
+    assert ((out.double().cpu() - ref).abs().max() / ref.abs().max()).item() < tol
+    lat = ops.drr_fwd(vd, 2, exp_mode=False, out_scale=1.0 / shape[3])
+    refm = vol.double().mean(dim=3)
+    assert ((lat.double().cpu() - refm).abs().max() / refm.abs().max().clamp_min(1e-3)).item() < (1e-5 if dtype == torch.float32 else 2e-2)
+
+
 def test_drr_full_size_linearity_and_checksum():
     """256^3 (BASELINE full size): mean projection is linear, and sum over the projection equals the
     scaled sum over the volume (size-independent properties; no CPU oracle run needed)."""
@@ -1675,9 +1697,11 @@ def test_bench_runs_the_ddp_path_over_rccl_on_one_gpu():
     DDP bucket views and all-reduce hooks over the HIP autograd Functions, barrier + max-over-ranks timing - so that the first
     RCCL initialisation does not happen on the driver's 8-GPU run (reference: direct_regression/train_direct_4gpu.py:25-37, :146).
     A world-size-1 all-reduce moves no data over xGMI: the step time must stay within 3 % of the plain single-GPU run."""
-    common = ["--gpus", "1", "--steps", "10", "--warmup", "3", "--no-cpu-baseline", "--no-extra", "--no-profile"]
-    plain = _run_bench(common)
-    ddp = _run_bench(common + ["--ddp"])
+    common = ["--gpus", "1", "--steps", "20", "--warmup", "3", "--no-cpu-baseline", "--no-extra", "--no-profile"]
+    # alternating runs, best of two each: run-to-run spread of a 20-step measurement on one box is ~2 % (clock / placement)
+    runs = [_run_bench(common + (["--ddp"] if i % 2 == 0 else [])) for i in range(4)]
+    ddp = min(runs[0::2], key=lambda d: d["ms_per_step"])
+    plain = min(runs[1::2], key=lambda d: d["ms_per_step"])
     assert ddp["dist_backend"] == "nccl" and ddp["rccl_ranks"] == 1 and ddp["nccl_version"], ddp
     assert ddp["ddp"]["gradient_as_bucket_view"] and ddp["n_gpus"] == 1
     assert "dist_backend" not in plain
