@@ -27,7 +27,7 @@ struct OptionSlot {
 const OptionSlot kOptionTable[hvc::kOptCount] = {
     {"HVC_ATTN_FWD_ROWS", 0, 0},   {"HVC_ATTN_FWD_WAVES", 0, 0},  {"HVC_ATTN_BWD_WAVES", 0, 0},    {"HVC_ATTN_EXTRA_LDS", 0, 0},
     {"HVC_ATTN_PIPE", 1, 0},    {"HVC_GEMM_PERSISTENT", 1, 0}, {"HVC_GEMM_STAGGER", 0, 0},      {"HVC_GEMM_HALF_TILE", 1, 0},
-    {"HVC_FP8_MX", 0, 0},          {"HVC_CONV_FORCE_ADDR64", 0, 0},
+    {"HVC_FP8_MX", 0, 0},          {"HVC_CONV_FORCE_ADDR64", 0, 0}, {"HVC_LOSS_FUSED", 1, 0},
 };
 std::atomic<int> g_options[hvc::kOptCount];
 // environment -> initial values, once, while the library is being loaded (before any launch and before any other thread can call in)

@@ -21,6 +21,7 @@ enum Option {
     kOptGemmHalfTile,        // HVC_GEMM_HALF_TILE    1 = 64 x 128 tiles on shapes that under-fill the chip (default)
     kOptFp8Mx,               // HVC_FP8_MX            1 = 32x32x64 f8f6f4 forward (round-3 experiment kernel)
     kOptConvForceAddr64,     // HVC_CONV_FORCE_ADDR64 1 = 64-bit addressed gather on every convolution (test hook)
+    kOptLossFused,           // HVC_LOSS_FUSED        1 = one-pass SSIM + L1 kernels for the 11-voxel window (default), 0 = three axis passes
     kOptCount
 };
 int option(Option o);

@@ -11,6 +11,8 @@
 //             dL/dp = l1_w sign(p-t)/n - ssim_w/n * (box(GA) + 2 p box(GPP) + t box(GPT)).
 #include "hvc_common.hip.h"
 #include "hvc_kernels.h"
+#include <initializer_list>
+#include <type_traits>
 
 namespace hvc {
 namespace {
@@ -270,6 +272,207 @@ __global__ __launch_bounds__(256) void ssim_grad_kernel(const float* __restrict_
     }
 }
 
+// ---- fused 11^3 box filter + point function: ONE pass over the volume (round 4) ------------------------------------------------
+// The three-pass pipeline above moves 27 volumes through HBM for 5 that the operation needs (two inputs read, three maps
+// written): rocprofv3 round 3 = 8.76x the algorithmic traffic at 0.08 of the HBM roof.  Here a workgroup owns a 16 x 16 column of
+// (h, w) positions and marches along D: per input plane it stages the 26 x 26 halo tile of its source maps in LDS, box-sums the
+// NQ channel maps along W (two outputs per thread from twelve staged values) and along H (through a second LDS tile), and every
+// thread keeps the last eleven (W, H)-summed planes of its own (h, w) position in REGISTERS (NQ x 11 values, static slots: the
+// plane loop is unrolled by eleven), so that the window sum along D, the SSIM point function (forward) or the combination into
+// dpred (backward) follow without another trip to memory.  Every sum is the same ascending sum over the same zero-padded window,
+// axis by axis (W, then H, then D), as in the three-pass kernels: maps and gradients are bit-identical to theirs.
+// Traffic: inputs with a 26^2 / 16^2 halo factor (L2 absorbs most of it), outputs once.
+struct FusedBoxArgs {
+    const float* in0; const float* in1; const float* in2;   // forward: pred, target, -; backward: the three derivative maps
+    const float* pred; const float* target;                  // backward: point values for the combination
+    float* out;                // forward: gmaps [3][nvox]; backward: dpred [nvox]
+    float* partial;            // forward: [2 * gridDim.x] block sums of S and |p - t|
+    const float* gscale;       // backward
+    int B, D, H, W, nzc, dchunk, tiles_h, tiles_w;
+    float inv_win, l1_w, ssim_w;
+};
+template <bool FWD>
+__global__ __launch_bounds__(256) void ssim_fused_kernel(const FusedBoxArgs a) {
+    constexpr int TH = 16, TW = 16, R = 5, AH = TH + 2 * R, AW = TW + 2 * R, AP = AW + 2;      // staged tile 26 x 26 (row pitch 28)
+    constexpr int NS = FWD ? 2 : 3;               // staged source maps
+    constexpr int NQ = FWD ? 5 : 3;               // box-filtered channels
+    constexpr int NE = (AH * AW + 255) / 256;     // staged elements per thread and map
+    __shared__ float As[NS][AH][AP];
+    __shared__ float Bs[NQ][AH][TW];
+    __shared__ float red[2][4];
+    const int tid = threadIdx.x;
+    int bid = blockIdx.x;
+    const int tw = bid % a.tiles_w; bid /= a.tiles_w;
+    const int th = bid % a.tiles_h; bid /= a.tiles_h;
+    const int zc = bid % a.nzc;
+    const int b = bid / a.nzc;
+    const int h0 = th * TH, w0 = tw * TW;
+    const int zs = zc * a.dchunk, ze = min(a.D, zs + a.dchunk);      // output planes [zs, ze)
+    const int64_t HW = (int64_t)a.H * a.W, nvox = (int64_t)a.B * a.D * HW;
+    const int64_t vbase = (int64_t)b * a.D * HW;
+    const float* src[3] = {a.in0, a.in1, a.in2};
+
+    // staged elements of this thread: the same (row, column) of the halo tile in every plane
+    int eoff[NE];
+    bool eok[NE];
+    int erc[NE];
+#pragma unroll
+    for (int j = 0; j < NE; ++j) {
+        const int e = tid + 256 * j;
+        const int rr = e / AW, cc = e % AW;
+        const int hh = h0 - R + rr, ww = w0 - R + cc;
+        eok[j] = e < AH * AW && hh >= 0 && hh < a.H && ww >= 0 && ww < a.W;
+        eoff[j] = eok[j] ? hh * a.W + ww : 0;
+        erc[j] = e < AH * AW ? rr * AP + cc : -1;
+    }
+    float stage[NS][NE];
+    auto gload = [&](int z) {
+        const bool zok = z >= 0 && z < a.D;
+#pragma unroll
+        for (int m = 0; m < NS; ++m)
+#pragma unroll
+            for (int j = 0; j < NE; ++j) stage[m][j] = (zok && eok[j]) ? src[m][vbase + (int64_t)z * HW + eoff[j]] : 0.f;
+    };
+    // phase-1 item of this thread: halo row r1, output columns c1, c1 + 1
+    const bool p1 = tid < AH * (TW / 2);
+    const int r1 = tid / (TW / 2), c1 = 2 * (tid % (TW / 2));
+    const int ph = tid / TW, pw = tid % TW;                  // this thread's (h, w) position
+    const bool pok = h0 + ph < a.H && w0 + pw < a.W;
+    float ring[NQ][11];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+        for (int k = 0; k < 11; ++k) ring[q][k] = 0.f;
+    float accS = 0.f, accL = 0.f;
+    const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+    float el1 = 0.f, ess = 0.f, inv_n = 0.f;
+    if constexpr (!FWD) {
+        el1 = a.gscale ? a.gscale[0] * a.l1_w + a.gscale[1] : a.l1_w;
+        ess = a.gscale ? a.gscale[0] * a.ssim_w + a.gscale[2] : a.ssim_w;
+        inv_n = 1.f / (float)nvox;
+    }
+
+    int z = zs - R;
+    const int zend = ze + R;                                  // input planes [zs - 5, ze + 5)
+    gload(z);
+    // one input plane into ring slot K (compile-time: the ring lives in registers only with static slots)
+    auto plane = [&](auto k_tag) {
+        constexpr int k = decltype(k_tag)::value;
+        {
+            const bool zok = z >= 0 && z < a.D;               // uniform: a plane outside the volume contributes exact zeros
+            if (zok) {
+#pragma unroll
+                for (int m = 0; m < NS; ++m)
+#pragma unroll
+                    for (int j = 0; j < NE; ++j)
+                        if (erc[j] >= 0) (&As[m][0][0])[erc[j]] = stage[m][j];
+            }
+            __syncthreads();
+            if (z + 1 < zend) gload(z + 1);                   // next plane's loads fly under this plane's arithmetic
+            float mq[NQ];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) mq[q] = 0.f;
+            if (zok) {
+                if (p1) {                                      // W pass: two outputs from twelve staged values per source map
+                    float v[NS][12];
+#pragma unroll
+                    for (int m = 0; m < NS; ++m)
+#pragma unroll
+                        for (int x = 0; x < 12; ++x) v[m][x] = As[m][r1][c1 + x];
+#pragma unroll
+                    for (int jo = 0; jo < 2; ++jo) {
+                        float s[NQ];
+#pragma unroll
+                        for (int q = 0; q < NQ; ++q) s[q] = 0.f;
+#pragma unroll
+                        for (int x = jo; x < jo + 11; ++x) {
+                            if constexpr (FWD) {
+                                const float pa = v[0][x], tb = v[1][x];
+                                s[0] += pa; s[1] += tb; s[2] += pa * pa; s[3] += tb * tb; s[4] += pa * tb;
+                            } else {
+                                s[0] += v[0][x]; s[1] += v[1][x]; s[2] += v[2][x];
+                            }
+                        }
+#pragma unroll
+                        for (int q = 0; q < NQ; ++q) Bs[q][r1][c1 + jo] = s[q];
+                    }
+                }
+                if constexpr (FWD) {
+                    if (pok && z >= zs && z < ze) accL += fabsf(As[0][ph + R][pw + R] - As[1][ph + R][pw + R]);
+                }
+            }
+            __syncthreads();
+            if (zok) {                                         // H pass: eleven rows of the W-summed tile
+#pragma unroll
+                for (int dh = 0; dh < 11; ++dh)
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) mq[q] += Bs[q][ph + dh][pw];
+            }
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) ring[q][k] = mq[q];
+            const int d = z - R;                              // the output plane whose window ends with this input plane
+            if (d >= zs && pok) {
+                float m[NQ];
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) m[q] = 0.f;
+#pragma unroll
+                for (int x = 1; x <= 11; ++x)                 // ascending along D: slot k + 1 holds the oldest plane, slot k the newest
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) m[q] += ring[q][(k + x) % 11];
+                const int64_t idx = vbase + (int64_t)d * HW + (int64_t)(h0 + ph) * a.W + (w0 + pw);
+                if constexpr (FWD) {
+                    const float mu_a = m[0] * a.inv_win, mu_b = m[1] * a.inv_win, epp = m[2] * a.inv_win, ett = m[3] * a.inv_win, ept = m[4] * a.inv_win;
+                    const float N1 = 2.f * mu_a * mu_b + C1, N2 = 2.f * (ept - mu_a * mu_b) + C2;
+                    const float D1 = mu_a * mu_a + mu_b * mu_b + C1, D2 = (epp - mu_a * mu_a) + (ett - mu_b * mu_b) + C2;
+                    const float inv = 1.f / (D1 * D2);
+                    const float S = (N1 * N2) * inv;
+                    a.out[idx] = 2.f * mu_b * (N2 - N1) * inv + 2.f * mu_a * S * (1.f / D2 - 1.f / D1);   // dS/dmu_p
+                    a.out[nvox + idx] = -S / D2;                                                            // dS/dE[p^2]
+                    a.out[2 * nvox + idx] = 2.f * N1 * inv;                                                 // dS/dE[pt]
+                    accS += S;
+                } else {
+                    const float pv = a.pred[idx], tv = a.target[idx];
+                    const float dS = (m[0] + 2.f * pv * m[1] + tv * m[2]) * a.inv_win;
+                    const float diff = pv - tv;
+                    const float sgn = diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f);
+                    a.out[idx] = inv_n * (el1 * sgn - ess * dS);
+                }
+            }
+            ++z;
+        }
+    };
+    auto run11 = [&](auto... ks) { (void)std::initializer_list<int>{((z < zend ? plane(ks) : (void)0), 0)...}; };
+    while (z < zend)
+        run11(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{}, std::integral_constant<int, 3>{},
+              std::integral_constant<int, 4>{}, std::integral_constant<int, 5>{}, std::integral_constant<int, 6>{}, std::integral_constant<int, 7>{},
+              std::integral_constant<int, 8>{}, std::integral_constant<int, 9>{}, std::integral_constant<int, 10>{});
+    if constexpr (FWD) {
+        accS = wave_sum(accS);
+        accL = wave_sum(accL);
+        const int lane = tid & 63, wave = tid >> 6;
+        if (lane == 0) { red[0][wave] = accS; red[1][wave] = accL; }
+        __syncthreads();
+        if (tid == 0) {
+            a.partial[2 * blockIdx.x] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+            a.partial[2 * blockIdx.x + 1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+        }
+    }
+}
+
+// grid of the fused kernel: (batch, D chunk, 16 x 16 tiles); D is cut into chunks (each re-reads a 10-plane halo) only as far as
+// needed to put ~1024 workgroups on the chip, and never below 32 planes per chunk
+static void fused_grid(FusedBoxArgs& f) {
+    f.tiles_h = (f.H + 15) / 16;
+    f.tiles_w = (f.W + 15) / 16;
+    const int64_t cols = (int64_t)f.B * f.tiles_h * f.tiles_w;
+    int nzc = (int)((1024 + cols - 1) / cols);
+    const int maxc = f.D / 32 > 0 ? f.D / 32 : 1;
+    if (nzc > maxc) nzc = maxc;
+    if (nzc < 1) nzc = 1;
+    f.dchunk = (f.D + nzc - 1) / nzc;
+    f.nzc = (f.D + f.dchunk - 1) / f.dchunk;
+}
+
 int grid_for(int64_t work) {
     int64_t blocks = (work + 255) / 256;
     if (blocks > 256 * 8) blocks = 256 * 8;
@@ -427,6 +630,17 @@ hipError_t ssim_l1_fwd_launch(const LossArgs& a, hipStream_t st) {
     float* Bw = a.workspace + 5 * nvox;
     float* partial = a.workspace + 10 * nvox;
     const int nblk = loss_blocks(nvox);
+    if (R == 5 && option(kOptLossFused) != 0) {      // the usual 11-voxel window: one fused pass (HVC_LOSS_FUSED=0 keeps the three-pass pipeline: tests compare them)
+        FusedBoxArgs f;
+        f.in0 = a.pred; f.in1 = a.target; f.in2 = nullptr; f.pred = a.pred; f.target = a.target;
+        f.out = a.gmaps; f.partial = A; f.gscale = nullptr;
+        f.B = a.B; f.D = a.D; f.H = a.H; f.W = a.W; f.inv_win = inv_win; f.l1_w = a.l1_w; f.ssim_w = a.ssim_w;
+        fused_grid(f);
+        const int nb = f.B * f.nzc * f.tiles_h * f.tiles_w;
+        hipLaunchKernelGGL((ssim_fused_kernel<true>), dim3(nb), dim3(256), 0, st, f);
+        hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(256), 0, st, A, nb, a.out, 1.0 / (double)nvox, a.l1_w, a.ssim_w);
+        return hipGetLastError();
+    }
     const bool w4 = R == 5 && a.W % 4 == 0 && ((reinterpret_cast<uintptr_t>(a.pred) | reinterpret_cast<uintptr_t>(a.target) | reinterpret_cast<uintptr_t>(A)) & 15) == 0;
     if (w4) hipLaunchKernelGGL(ssim_pass_w4_kernel, dim3(grid_for(nvox / 4)), dim3(256), 0, st, a.pred, a.target, A, nvox / a.W, a.W);
     else hipLaunchKernelGGL(ssim_pass_w_kernel, dim3(grid_for(nvox)), dim3(256), 0, st, a.pred, a.target, A, nvox / a.W, a.W, R);
@@ -444,6 +658,15 @@ hipError_t ssim_l1_bwd_launch(const LossArgs& a, hipStream_t st) {
     const float inv_win = 1.f / ((float)a.window * a.window * a.window);
     float* A = a.workspace;
     float* Bw = a.workspace + 3 * nvox;
+    if (R == 5 && option(kOptLossFused) != 0) {
+        FusedBoxArgs f;
+        f.in0 = a.gmaps; f.in1 = a.gmaps + nvox; f.in2 = a.gmaps + 2 * nvox; f.pred = a.pred; f.target = a.target;
+        f.out = a.dpred; f.partial = nullptr; f.gscale = a.gscale;
+        f.B = a.B; f.D = a.D; f.H = a.H; f.W = a.W; f.inv_win = inv_win; f.l1_w = a.l1_w; f.ssim_w = a.ssim_w;
+        fused_grid(f);
+        hipLaunchKernelGGL((ssim_fused_kernel<false>), dim3(f.B * f.nzc * f.tiles_h * f.tiles_w), dim3(256), 0, st, f);
+        return hipGetLastError();
+    }
     const bool w4 = R == 5 && a.W % 4 == 0 && ((reinterpret_cast<uintptr_t>(a.gmaps) | reinterpret_cast<uintptr_t>(A)) & 15) == 0;
     if (w4) hipLaunchKernelGGL(box_w4_kernel, dim3(grid_for(3 * nvox / 4)), dim3(256), 0, st, a.gmaps, A, 3 * nvox / a.W, a.W);
     else hipLaunchKernelGGL(box_axis_kernel, dim3(grid_for(3 * nvox)), dim3(256), 0, st, a.gmaps, A, 3 * nvox, a.W, (int64_t)1, R);

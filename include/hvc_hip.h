@@ -58,7 +58,7 @@ int hvc_clear_seed_counter_if(const uint32_t* device_counter);
  * environment variables that give the initial values when the library is loaded: HVC_ATTN_FWD_ROWS (0 | 32 | 64),
  * HVC_ATTN_FWD_WAVES (0 | 4 | 8), HVC_ATTN_BWD_WAVES (0 | 4 | 8), HVC_ATTN_PIPE (1 | 0 | 2), HVC_ATTN_EXTRA_LDS (bytes),
  * HVC_GEMM_PERSISTENT (1 | 0), HVC_GEMM_STAGGER (>= 0), HVC_GEMM_HALF_TILE (1 | 0), HVC_FP8_MX (0 | 1),
- * HVC_CONV_FORCE_ADDR64 (0 | 1).  Values are atomic ints read at launch time, safe to set from any thread between launches;
+ * HVC_CONV_FORCE_ADDR64 (0 | 1), HVC_LOSS_FUSED (1 | 0).  Values are atomic ints read at launch time, safe to set from any thread between launches;
  * unknown names and negative values return HVC_E_BADARG. */
 int hvc_set_option(const char* name, int value);
 int hvc_get_option(const char* name, int* value);

@@ -371,7 +371,7 @@ def test_options_are_declared_in_the_header_and_bound():
     lib = _lib.load()
     hdr = open(os.path.join(ROOT, "include", "hvc_hip.h")).read()
     for name in ("HVC_ATTN_FWD_ROWS", "HVC_ATTN_FWD_WAVES", "HVC_ATTN_BWD_WAVES", "HVC_ATTN_PIPE", "HVC_GEMM_PERSISTENT",
-                 "HVC_GEMM_STAGGER", "HVC_GEMM_HALF_TILE", "HVC_FP8_MX", "HVC_CONV_FORCE_ADDR64", "HVC_ATTN_EXTRA_LDS"):
+                 "HVC_GEMM_STAGGER", "HVC_GEMM_HALF_TILE", "HVC_FP8_MX", "HVC_CONV_FORCE_ADDR64", "HVC_ATTN_EXTRA_LDS", "HVC_LOSS_FUSED"):
         assert name in hdr, name
         old = ops.get_option(name)
         with ops.options(**{name: 4}):

@@ -1574,6 +1574,34 @@ def test_ssim_l1_loss_random_sizes_and_weights(seed):
             DirectRegressionLoss()(small, small)
 
 
+@pytest.mark.parametrize("shape", [(1, 11, 11, 11), (2, 40, 33, 50), (1, 70, 16, 130), (2, 128, 128, 128), (1, 96, 200, 72)])
+def test_ssim_fused_pass_matches_three_pass_pipeline(shape, hvc_option):
+    """The one-pass SSIM + L1 kernels (16 x 16 columns marching along D, eleven (W, H)-summed planes per position in registers;
+    model_direct.py:88-131) against the three-axis-pass pipeline they replace (HVC_LOSS_FUSED=0, the form the oracle tests have
+    covered since round 1): every window sum is the same ascending zero-padded sum axis by axis; what differs is where hipcc
+    contracts a multiply-add into an fma inside the two kernels' point functions (one-ulp differences that the 1 / (D1 D2) factor
+    of the derivative maps passes on), so maps and dpred are held to 1e-5 of their largest entry and the scalar losses - block sums
+    over a different block partition - to 2e-6.  Shapes: the smallest legal volume, extents that are not multiples of the 16 x 16
+    tile, D cut into chunks with halo planes, the 128^3 benchmark size."""
+    from hvc import ops
+    B, D, H, W = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    p = (torch.rand(B, D, H, W, generator=g) * 2 - 1).to(dev())
+    t = (p + 0.3 * torch.randn(B, D, H, W, generator=g).to(dev())).clamp(-1, 1)
+    gs = torch.tensor([0.7, 0.2, -0.4], device=dev())
+    res = {}
+    for fused in (0, 1):
+        hvc_option("HVC_LOSS_FUSED", fused)
+        out, gmaps = ops.ssim_l1_fwd(p, t, 11, 1.0, 0.5)
+        dp = ops.ssim_l1_bwd(p, t, gmaps, gs, 11, 1.0, 0.5)
+        res[fused] = (out.clone(), gmaps.clone(), dp.clone())
+    for name, i in (("derivative maps", 1), ("dpred", 2)):
+        e = ((res[0][i] - res[1][i]).abs().max() / res[0][i].abs().max()).item()
+        _note(f"ssim_fused/{name}/{'x'.join(map(str, shape))}", e, 1e-5)
+        assert e < 1e-5, (name, e)
+    assert torch.allclose(res[0][0], res[1][0], rtol=2e-6, atol=1e-7), (res[0][0], res[1][0])
+
+
 @pytest.mark.parametrize("seed", range(8))
 def test_attention_forward_64_row_kernel_matches_oracle_and_32_row_kernel(seed, hvc_option):
     """attn_fwd2_kernel (two query blocks per wavefront, 32-key tiles; picked automatically from 512 workgroups up) pinned
