@@ -1360,7 +1360,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void attn_bwd_dq_ke
 // backward: dK, dV
 // ---------------------------------------------------------------------------------
 // (Round 4 built a software-pipelined form of this kernel - the dV / dK products of slice j-1 issued under the vector work of slice
-// j, Q / dO four tiles deep by LDS-DMA, commit afce664 - bit-compatible lots, parity green, and +-0 % on every BASELINE shape
+// j, Q / dO four tiles deep by LDS-DMA, commits afce664 and (with every LDS operand requested a sub-step ahead) its successor -
+// bit-compatible lots, parity green, and +-0 % on every BASELINE shape
 // (profiles/r04_attention_pipelined_dkv_experiment.txt): with 438 instructions per 32 MFMAs the kernel is bound by the rate at
 // which a SIMD issues instructions of ANY kind (~5 cycles each with two wavefronts), not by the order they are issued in.)
 // WAVES = 4: 128 keys per workgroup, two workgroups per CU.  WAVES = 8 (round 3; chosen by launch_bwd): 256 keys per
@@ -1639,349 +1640,6 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void attn_bwd_dkv_k
         }
 }
 
-// ---------------------------------------------------------------------------------
-// backward: dK, dV, software-pipelined (round 4; bf16, 16-byte addressable operands, LDS-DMA tiles)
-// ---------------------------------------------------------------------------------
-// Same arithmetic and dropout lots as attn_bwd_dkv_kernel (32 keys per wavefront in registers, 64-query tiles, two 32-query
-// slices per tile), with the slices skewed so that every stretch of the sweep carries matrix and vector work that do not depend
-// on each other.  In the phase-separated kernel a wavefront runs per slice: 8 MFMAs (S, dP) -> ~120 vector instructions (exp,
-// keep test, dS) -> 8 MFMAs (dV, dK), each phase waiting for the one before; matrix and vector time are about EQUAL there (42 % /
-// 49 % of the SIMD, profiles/r03_pmc_*), so running them one after the other is what bounds it.  Here slice j's vector work
-// runs between the MFMAs of two other slices:
-//   step j :  S / dP chains of slice j (8 MFMA), then   dV / dK products of slice j-1 (8 MFMA)   ||   exp, keep test, dS of slice j
-// in four sub-steps of 2 MFMAs + a quarter of the vector work, fenced so that hipcc keeps the interleave and does not hoist
-// every LDS read.  (Running the chains of slice j+1 under the vector work as well needs a second pair of S / dP accumulators:
-// 32 registers more than the 256 this kernel has beside its 64 dK / dV accumulators and 32 K / V fragment registers - it spilt.)
-// Q / dO tiles (and the row constants) sit four tiles deep in LDS (slices of tiles t-1 and t are read during tile t while tiles
-// t+1 and t+2 land by LDS-DMA, up to two tiles ahead); dropout lots two tiles deep, generated between the slices.
-template <int D, bool DROP, int WAVES>
-__global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void attn_bwdp_dkv_kernel(const AttnArgs a_in) {
-    using T = bf16;
-    constexpr int KB = 32 * WAVES;                  // keys per workgroup
-    constexpr int LS = WAVES * kLotPart;            // lots per tile row
-    constexpr int TILE = kKT * D;
-    constexpr int NB = 4;                           // Q / dO / row-constant ring depth
-    AttnArgs a = a_in;
-    a.seed_lo = seed_with_counter(a_in.seed_lo, a_in.seed_ctr);
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    bf16* lds = reinterpret_cast<bf16*>(smem);                             // [NB][Q|dO][TILE]
-    float* stat = reinterpret_cast<float*>(lds + NB * 2 * TILE);           // [NB][lse2|delta][kKT]
-    uint16_t* lots = reinterpret_cast<uint16_t*>(stat + NB * 2 * kKT);     // [2][64 q][LS]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const bool loader = WAVES == 4 || tid < 256;    // the tile loaders are written for 256 threads
-    const int r = lane & 31, h = lane >> 5;
-
-    const int nkb = (a.Nk + KB - 1) / KB;
-    const int nwg = nkb * a.B * a.H;
-    const int split = blockIdx.x / nwg;
-    int bh, kb;
-    block_map(blockIdx.x % nwg, a.B * a.H, nkb, bh, kb);
-    const int b = bh / a.H, hh = bh % a.H;
-    const T* qp = reinterpret_cast<const T*>(a.q) + b * a.q_sb + hh * a.q_sh;
-    const T* kp = reinterpret_cast<const T*>(a.k) + b * a.k_sb + hh * a.k_sh;
-    const T* vp = reinterpret_cast<const T*>(a.v) + b * a.v_sb + hh * a.v_sh;
-    const T* dop = reinterpret_cast<const T*>(a.dout) + b * a.do_sb + hh * a.do_sh;
-    T* dkp = reinterpret_cast<T*>(a.dk) + b * a.dk_sb + hh * a.dk_sh;
-    T* dvp = reinterpret_cast<T*>(a.dv) + b * a.dv_sb + hh * a.dv_sh;
-
-    const int k0 = kb * KB + wave * 32;
-    const int krow = k0 + r;
-    const bool kvalid = krow < a.Nk;
-    const int krow_c = kvalid ? krow : a.Nk - 1;
-    const float sl2 = a.scale * kLog2e;
-    bf16x8 kf[1][D / 16], vf[1][D / 16];
-    load_row_frags_scaled<T, 1, D / 16, true>(kp + (int64_t)krow_c * a.k_sn, h, kvalid, sl2, kf);
-    load_row_frags<T, 1, D / 16, true>(vp + (int64_t)krow_c * a.v_sn, h, kvalid, vf);
-
-    TileLoader<T, D, true> ql, dl;
-    static_assert(TileLoader<T, D, true>::DMA, "the pipelined backward takes its tiles by LDS-DMA");
-    auto Qt = [&](int buf) { return lds + (buf * 2 + 0) * TILE; };
-    auto Dt = [&](int buf) { return lds + (buf * 2 + 1) * TILE; };
-    const int nt_all = (a.Nq + kKT - 1) / kKT;
-    const int per_split = (nt_all + a.qsplit - 1) / a.qsplit;
-    const int t_begin = split * per_split;
-    const int nt = min(nt_all, t_begin + per_split);      // this workgroup sweeps query tiles [t_begin, nt)
-    float st_l = 0.f, st_d = 0.f;
-    bool st_ok = false;
-    auto issue_stat = [&](int t) {
-        if (tid < kKT) {
-            const int q = t * kKT + tid;
-            st_ok = q < a.Nq;
-            const int qc = st_ok ? q : a.Nq - 1;
-            st_l = a.lse[(int64_t)bh * a.Nq + qc];
-            st_d = a.delta[(int64_t)bh * a.Nq + qc];
-        }
-    };
-    auto commit_stat = [&](int buf) {
-        if (tid < kKT) {
-            stat[(buf * 2 + 0) * kKT + tid] = st_ok ? -st_l * kLog2e : -INFINITY;      // out-of-range query rows: p = exp2(-inf) = 0
-            stat[(buf * 2 + 1) * kKT + tid] = st_ok ? -st_d * (DROP ? 1.f / a.keep_scale : 1.f) : 0.f;
-        }
-    };
-    auto gen_lots = [&](int t, int buf) {
-        if constexpr (DROP) {
-            const int qlr = tid / WAVES, part = tid % WAVES;
-            const int q = min(t * kKT + qlr, a.Nq - 1);
-            const uint32_t rk0 = drop_rowkey(a, bh, q), tadd = (uint32_t)((KB / 64) * kb + (part >> 1)) * kTileAdd;
-            const uint32_t rk[2] = {(rk0 + tadd) ^ drop_grp_a(part & 1), ((rk0 ^ kGrpH) + tadd) ^ drop_grp_a(part & 1)};
-            uint32_t* dst = reinterpret_cast<uint32_t*>(lots + ((size_t)buf * kKT + qlr) * LS + kLotPart * part);
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const uint32_t m = rk[u & 1] ^ drop_grp_b(u >> 1);
-                drop_lots4(m, dst[2 * u], dst[2 * u + 1]);
-            }
-        }
-    };
-
-    // per-lane LDS addresses (see attn_bwd_dkv_kernel)
-    const bf16* raddr[D / 16];
-    const bf16* taddr[D / 32][2];
-#pragma unroll
-    for (int s = 0; s < D / 16; ++s) raddr[s] = lds + row_frag_lane_off<D>(16 * s, lane);
-#pragma unroll
-    for (int dt = 0; dt < D / 32; ++dt) {
-        int oa, ob;
-        tr_frag_lane_off<D, true>(32 * dt, lane, oa, ob);
-        taddr[dt][0] = lds + oa;
-        taddr[dt][1] = lds + ob;
-    }
-    const float* stat_lane = stat + 4 * h;                            // row constants of query rows 4h + {0..3} (+ 8g + 32qt)
-    const uint16_t* lots_lane = lots + 4 * h * LS + wave * kLotPart + r;
-    const int ts = drop_ts(a);
-
-    f32x16 dk[D / 32], dv[D / 32];
-#pragma unroll
-    for (int dt = 0; dt < D / 32; ++dt)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { dk[dt][i] = 0.f; dv[dt][i] = 0.f; }
-
-    // prologue: tiles t_begin (also into the ring slot BEFORE it: the first step multiplies that slot's contents by zero
-    // fragments, so they must be finite) and t_begin + 1, their row constants, the lots of tile t_begin
-    if (loader) {
-        ql.init(qp, a.q_sn, t_begin * kKT, tid);
-        dl.init(dop, a.do_sn, t_begin * kKT, tid);
-        ql.issue(qp, a.q_sn, t_begin * kKT, a.Nq, tid, Qt(0));
-        dl.issue(dop, a.do_sn, t_begin * kKT, a.Nq, tid, Dt(0));
-        ql.issue(qp, a.q_sn, (t_begin + 1) * kKT, a.Nq, tid, Qt(1));
-        dl.issue(dop, a.do_sn, (t_begin + 1) * kKT, a.Nq, tid, Dt(1));
-        TileLoader<T, D, true> qz, dz;
-        qz.init(qp, a.q_sn, t_begin * kKT, tid);
-        dz.init(dop, a.do_sn, t_begin * kKT, tid);
-        qz.issue(qp, a.q_sn, t_begin * kKT, a.Nq, tid, Qt(3));
-        dz.issue(dop, a.do_sn, t_begin * kKT, a.Nq, tid, Dt(3));
-    }
-    issue_stat(t_begin);
-    commit_stat(0);
-    issue_stat(t_begin + 1);
-    commit_stat(1);
-    gen_lots(t_begin, 0);
-    ql.wait();
-    __syncthreads();
-
-    // packed P / dS fragments of the slice before the current one (its dV / dK products run under the current slice's vector work)
-    bf16x8 pf_prev[2], dsf_prev[2];
-#pragma unroll
-    for (int x = 0; x < 2; ++x) {
-        pf_prev[x] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-        dsf_prev[x] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-    }
-
-    // One step = one slice (tile in ring slot T4, half QT): its S / dP chains (8 MFMAs), then its vector work in four sub-steps,
-    // each with a quarter of the dV / dK products of the slice BEFORE it (slot PBUF, half PQT) in front.
-    auto step = [&](auto t4_tag, auto qt_tag) {
-        constexpr int T4 = decltype(t4_tag)::value, QT = decltype(qt_tag)::value;
-        constexpr int PBUF = QT == 0 ? (T4 + 3) & 3 : T4, PQT = QT ^ 1;            // slice before: (t - 1, 1) or (t, 0)
-        constexpr int LB = T4 & 1;                                                 // lots buffer of this tile
-        constexpr int CQ = (T4 * 2 + 0) * TILE + 32 * QT * D, CD = (T4 * 2 + 1) * TILE + 32 * QT * D;
-        constexpr int PQ = (PBUF * 2 + 0) * TILE + 32 * PQT * D, PD = (PBUF * 2 + 1) * TILE + 32 * PQT * D;
-        f32x16 s_cur, dp_cur;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {      // seeds: -lse2 of the slice's query rows (and -delta without dropout), straight from LDS
-            const int ro = 32 * QT + 8 * g;
-            const f32x4 l4 = *reinterpret_cast<const f32x4*>(stat_lane + ((T4 * 2 + 0) * kKT + ro));
-#pragma unroll
-            for (int j = 0; j < 4; ++j) s_cur[4 * g + j] = l4[j];
-            if constexpr (!DROP) {
-                const f32x4 d4 = *reinterpret_cast<const f32x4*>(stat_lane + ((T4 * 2 + 1) * kKT + ro));
-#pragma unroll
-                for (int j = 0; j < 4; ++j) dp_cur[4 * g + j] = d4[j];
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) dp_cur[4 * g + j] = 0.f;
-            }
-        }
-#pragma unroll
-        for (int ks = 0; ks < D / 16; ++ks) {
-            const bf16x8 qa = *reinterpret_cast<const bf16x8*>(raddr[ks] + CQ);
-            const bf16x8 da = *reinterpret_cast<const bf16x8*>(raddr[ks] + CD);
-            s_cur = mfma32(qa, kf[0][ks], s_cur);
-            dp_cur = mfma32(da, vf[0][ks], dp_cur);
-        }
-        float pd[16], ds[16];
-        bf16x8 pf_cur[2], dsf_cur[2];
-        // LDS operands of one sub-step: the transposed dO / Q fragments of its share of the products, the lots and -delta of its four
-        // query rows.  They are requested one sub-step AHEAD (the fences below stop hipcc from hoisting reads on its own, and a read
-        // issued in the sub-step that uses it exposes the full LDS latency four times per slice - the first form of this kernel did).
-        constexpr int PARTS = 2 * (D / 32), PPS = PARTS / 4 > 0 ? PARTS / 4 : 1;      // product parts per sub-step (d = 64: 1)
-        struct SubOps { bf16x8 dof[PPS], qfr[PPS]; uint32_t lot[4]; f32x4 nd4; };
-        auto request = [&](int k, SubOps& o) {
-#pragma unroll
-            for (int pp = k * PARTS / 4; pp < (k + 1) * PARTS / 4; ++pp) {
-                const int s2 = pp / (D / 32), dt = pp % (D / 32);
-                const int TO = 16 * s2 * D;
-                o.dof[pp - k * PARTS / 4] = tr_frag_at(taddr[dt][0] + (PD + TO), taddr[dt][1] + (PD + TO));
-                o.qfr[pp - k * PARTS / 4] = tr_frag_at(taddr[dt][0] + (PQ + TO), taddr[dt][1] + (PQ + TO));
-            }
-            if constexpr (DROP) {
-                const int ro = 32 * QT + 8 * k;
-                o.nd4 = *reinterpret_cast<const f32x4*>(stat_lane + ((T4 * 2 + 1) * kKT + ro));
-#pragma unroll
-                for (int j = 0; j < 4; ++j) o.lot[j] = lots_lane[(LB * kKT + ro + j) * LS];
-            }
-        };
-        SubOps cur, nxt;
-        request(0, cur);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (k + 1 < 4) request(k + 1, nxt);
-            // products of the slice before: (s2, dt) pairs spread over the four sub-steps
-#pragma unroll
-            for (int pp = k * PARTS / 4; pp < (k + 1) * PARTS / 4; ++pp) {
-                const int s2 = pp / (D / 32), dt = pp % (D / 32);
-                dv[dt] = mfma32(pf_prev[s2], cur.dof[pp - k * PARTS / 4], dv[dt]);
-                dk[dt] = mfma32(dsf_prev[s2], cur.qfr[pp - k * PARTS / 4], dk[dt]);
-            }
-            // vector work of this slice, query rows 8 k + 4 h + {0..3} (accumulator registers 4k .. 4k+3)
-            {
-                float p[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) p[j] = __builtin_amdgcn_exp2f(s_cur[4 * k + j]);
-                if constexpr (DROP) {
-#pragma unroll
-                    for (int j = 0; j < 4; j += 2) {
-                        f32x2 pd2;
-#pragma unroll
-                        for (int e = 0; e < 2; ++e) {
-                            const bool keep = (int16_t)cur.lot[j + e] >= (int16_t)ts;
-                            float pdv = keep ? p[j + e] : 0.f;
-                            asm("" : "+v"(pdv));     // select in fp32, so that the bf16 conversions below stay packed pairs
-                            pd2[e] = pdv;
-                        }
-                        const f32x2 p2 = {p[j], p[j + 1]};
-                        const f32x2 dp2 = {dp_cur[4 * k + j], dp_cur[4 * k + j + 1]};
-                        const f32x2 nd2 = {cur.nd4[j], cur.nd4[j + 1]};
-                        const f32x2 ds2 = __builtin_elementwise_fma(pd2, dp2, p2 * nd2);
-                        pd[4 * k + j] = pd2[0]; pd[4 * k + j + 1] = pd2[1];
-                        ds[4 * k + j] = ds2[0]; ds[4 * k + j + 1] = ds2[1];
-                    }
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 4; j += 2) {
-                        const f32x2 p2 = {p[j], p[j + 1]};
-                        const f32x2 dp2 = {dp_cur[4 * k + j], dp_cur[4 * k + j + 1]};
-                        const f32x2 ds2 = p2 * dp2;
-                        pd[4 * k + j] = p2[0]; pd[4 * k + j + 1] = p2[1];
-                        ds[4 * k + j] = ds2[0]; ds[4 * k + j + 1] = ds2[1];
-                    }
-                }
-                if (k & 1) {            // eight rows complete: their packed fragments for the products of the NEXT step
-                    const int s2 = k >> 1;
-                    float x[8], y[8];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) { x[j] = pd[8 * s2 + j]; y[j] = ds[8 * s2 + j]; }
-                    bf16x8 im[1];
-                    acc_split<1>(x, im);
-                    pf_cur[s2] = im[0];
-                    acc_split<1>(y, im);
-                    dsf_cur[s2] = im[0];
-                }
-            }
-            cur = nxt;
-            __builtin_amdgcn_sched_barrier(0);
-        }
-#pragma unroll
-        for (int x = 0; x < 2; ++x) { pf_prev[x] = pf_cur[x]; dsf_prev[x] = dsf_cur[x]; }
-    };
-    // one query tile (ring slot T4 = (t - t_begin) & 3): fetch tile t+2, the two steps with the next tile's lots hashed between
-    // them, publish
-    auto tile_body = [&](auto t4_tag, int t) {
-        constexpr int T4 = decltype(t4_tag)::value;
-        if (loader) {
-            ql.issue(qp, a.q_sn, (t + 2) * kKT, a.Nq, tid, Qt((T4 + 2) & 3));
-            dl.issue(dop, a.do_sn, (t + 2) * kKT, a.Nq, tid, Dt((T4 + 2) & 3));
-        }
-        issue_stat(t + 2);
-        step(t4_tag, std::integral_constant<int, 0>{});
-        gen_lots(t + 1, (T4 + 1) & 1);
-        step(t4_tag, std::integral_constant<int, 1>{});
-        commit_stat((T4 + 2) & 3);
-        ql.wait();
-        __syncthreads();
-    };
-    using I0 = std::integral_constant<int, 0>;
-    using I1 = std::integral_constant<int, 1>;
-    using I2 = std::integral_constant<int, 2>;
-    using I3 = std::integral_constant<int, 3>;
-    int t = t_begin;
-    for (; t + 4 <= nt; t += 4) {
-        tile_body(I0{}, t);
-        tile_body(I1{}, t + 1);
-        tile_body(I2{}, t + 2);
-        tile_body(I3{}, t + 3);
-    }
-    const int rem = nt - t;                                // 0 .. 3 tiles left; the ring phase is 0 here
-    if (rem > 0) {
-        tile_body(I0{}, t);
-        if (rem > 1) {
-            tile_body(I1{}, t + 1);
-            if (rem > 2) tile_body(I2{}, t + 2);
-        }
-    }
-    // the products of the last slice (tile nt - 1, second half)
-    if (nt > t_begin) {
-        const int buf = (nt - 1 - t_begin) & 3;
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-            for (int dt = 0; dt < D / 32; ++dt) {
-                const int TO = (32 + 16 * s2) * D;
-                const bf16x8 dof = tr_frag_at(taddr[dt][0] + ((buf * 2 + 1) * TILE + TO), taddr[dt][1] + ((buf * 2 + 1) * TILE + TO));
-                const bf16x8 qfr = tr_frag_at(taddr[dt][0] + ((buf * 2 + 0) * TILE + TO), taddr[dt][1] + ((buf * 2 + 0) * TILE + TO));
-                dv[dt] = mfma32(pf_prev[s2], dof, dv[dt]);
-                dk[dt] = mfma32(dsf_prev[s2], qfr, dk[dt]);
-            }
-    }
-    // tiles: rows = key (registers), col = d (lane)
-    const float ks = DROP ? a.keep_scale : 1.f;
-    if (a.qsplit > 1) {   // fp32 partial slabs [dK|dV][split][bh][key][d]; summed in a fixed order by attn_dkv_reduce_kernel
-        const size_t slab = (size_t)a.B * a.H * a.Nk * D;
-        float* pk = a.dkv_partial + ((size_t)split * a.B * a.H + bh) * a.Nk * D;
-        float* pv = pk + (size_t)a.qsplit * slab;
-#pragma unroll
-        for (int dt = 0; dt < D / 32; ++dt)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int kk = k0 + acc_row(i, h);
-                if (kk < a.Nk) {
-                    pk[(size_t)kk * D + 32 * dt + r] = dk[dt][i] * a.scale * ks;
-                    pv[(size_t)kk * D + 32 * dt + r] = dv[dt][i] * ks;
-                }
-            }
-        return;
-    }
-#pragma unroll
-    for (int dt = 0; dt < D / 32; ++dt)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int kk = k0 + acc_row(i, h);
-            if (kk < a.Nk) {
-                dkp[(int64_t)kk * a.dk_sn + 32 * dt + r] = from_f<T>(dk[dt][i] * a.scale * ks);
-                dvp[(int64_t)kk * a.dv_sn + 32 * dt + r] = from_f<T>(dv[dt][i] * ks);
-            }
-        }
-}
-
 // dK / dV = sum over the query-range slices of the partial slabs (fixed order), cast and scattered to the strided outputs
 template <typename T, int D>
 __global__ __launch_bounds__(256) void attn_dkv_reduce_kernel(const AttnArgs a) {
@@ -2118,31 +1776,6 @@ hipError_t launch_bwd(const AttnArgs& a, hipStream_t st) {
         b.qsplit = attention_bwd_qsplit(a.B, a.H, a.Nq, a.Nk);
         if (b.qsplit > 1 && (!a.dkv_partial || a.partial_floats < (int64_t)2 * b.qsplit * a.B * a.H * a.Nk * D)) b.qsplit = 1;
         hipError_t e = hipSuccess;
-        if constexpr (CAN8 && HVC_ATTN_DMA) {
-            // software-pipelined form (256-key workgroups of eight wavefronts) wherever the 8-wavefront form would run;
-            // HVC_ATTN_PIPE=0 keeps the phase-separated kernels, =2 takes it on any grid (tests)
-            const int pipe = option(kOptAttnPipe);
-            if (pin != 4 && (pipe == 2 || (pipe == 1 && w8))) {
-                const int nkbp = (a.Nk + 255) / 256;
-                const size_t ldsp = (size_t)4 * 2 * kKT * D * sizeof(bf16) + 4 * 2 * kKT * sizeof(float) +
-                                    (DROP ? (size_t)2 * kKT * 8 * kLotPart * sizeof(uint16_t) : 0) + extra_lds();
-                auto kp8 = attn_bwdp_dkv_kernel<D, DROP, 8>;
-                e = set_lds(kp8, ldsp);
-                if (e != hipSuccess) return e;
-                hipLaunchKernelGGL(kp8, dim3(nkbp * a.B * a.H * b.qsplit), dim3(512), ldsp, st, b);
-                e = hipGetLastError();
-                if (e != hipSuccess) return e;
-                if (b.qsplit > 1) {
-                    size_t n = (size_t)a.B * a.H * a.Nk * D;
-                    int blocks = (int)((n + 255) / 256);
-                    if (blocks > 4096) blocks = 4096;
-                    hipLaunchKernelGGL((attn_dkv_reduce_kernel<T, D>), dim3(blocks), dim3(256), 0, st, b);
-                    e = hipGetLastError();
-                    if (e != hipSuccess) return e;
-                }
-                goto dq_phase;
-            }
-        }
         if constexpr (CAN8) {
             if (w8) {
                 auto k8 = attn_bwd_dkv_kernel<T, D, DROP, VEC, 8>;
@@ -2168,7 +1801,6 @@ hipError_t launch_bwd(const AttnArgs& a, hipStream_t st) {
             if (e != hipSuccess) return e;
         }
     }
-dq_phase:
     if (ph & 4) {
         const size_t lds = fwd_lds_bytes<T, D>() + extra_lds();
         if constexpr (sizeof(T) == 2 && VEC) {
