@@ -289,30 +289,46 @@ __global__ __launch_bounds__(256) void axis_adjoint_kernel(const float* __restri
 }
 
 // The same adjoint along a CONTIGUOUS axis (inner = 1: the W pass, which reads the whole fine gradient - 63 of every 64 bytes of
-// the resize backward at a 4x factor), fine % 4 == 0: a thread owns one coarse element and takes its candidate window as aligned
-// 16-byte loads (3 - 4 per thread; neighbouring threads' windows overlap and hit L1) instead of ~10 dependent 4-byte loads at a
-// 16-byte lane stride, which left the kernel bound by load issue at 0.14 of the HBM roof.  Same candidates, same order, same
-// weights as axis_adjoint_kernel: bit-identical sums.
+// the resize backward at a 4x factor), fine % 4 == 0, coarse <= 256, windows of <= 32 fine elements (factors up to ~12): a thread owns one coarse element and takes its candidate
+// window as aligned 16-byte loads (3 - 4 per thread; neighbouring threads' windows overlap and hit L1) instead of ~10 dependent
+// 4-byte loads at a 16-byte lane stride, and the interpolation weights of the window - the same for every row - come from a table
+// the workgroup builds once in LDS (window start + 32 weights per coarse index) instead of ~12 instructions per candidate.  Same
+// candidates, same ascending order, same weights (axis_w) as axis_adjoint_kernel: bit-identical sums.  Round 3: 0.14 of the HBM roof.
+constexpr int kAdjMaxCoarse = 256, kAdjWin = 32;      // table: 32 KB of LDS
 __global__ __launch_bounds__(256) void axis_adjoint_w4_kernel(const float* __restrict__ src, float* __restrict__ dst, int64_t outer, int fine,
                                                                int coarse, int ac) {
+    __shared__ __attribute__((aligned(16))) float wtab[kAdjMaxCoarse][kAdjWin];
+    __shared__ int c0tab[kAdjMaxCoarse], hitab[kAdjMaxCoarse];
     const AxisMap m = axis_map(coarse, fine, ac);
+    for (int i = threadIdx.x; i < coarse; i += 256) {
+        int lo, hi;
+        axis_range(i, m, fine, lo, hi);
+        const int c0 = lo & ~3;
+        if (hi > c0 + kAdjWin - 1) hi = c0 + kAdjWin - 1;      // (never on the factors this path serves: the launcher checks)
+        c0tab[i] = c0;
+        hitab[i] = hi;
+#pragma unroll 4
+        for (int x = 0; x < kAdjWin; ++x) {
+            const int f = c0 + x;
+            wtab[i][x] = (f >= lo && f <= hi) ? axis_w(f, i, m, coarse) : 0.f;
+        }
+    }
+    __syncthreads();
     const int64_t total = outer * coarse;
     for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
         const int i = (int)(idx % coarse);
         const int64_t o = idx / coarse;
-        int lo, hi;
-        axis_range(i, m, fine, lo, hi);
-        const float* s = src + o * fine;
+        const int c0 = c0tab[i], hi = hitab[i];
+        const float* s = src + o * fine + c0;
         float acc = 0.f;
-        for (int c = lo & ~3; c <= hi; c += 4) {
-            const f32x4 q = *reinterpret_cast<const f32x4*>(s + c);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int f = c + j;
-                if (f >= lo && f <= hi) {
-                    const float wgt = axis_w(f, i, m, coarse);
-                    if (wgt != 0.f) acc += wgt * q[j];
-                }
+        for (int cc = 0; cc < kAdjWin / 4; ++cc) {
+            if (c0 + 4 * cc <= hi) {
+                const f32x4 q = *reinterpret_cast<const f32x4*>(s + 4 * cc);
+                const f32x4 w = *reinterpret_cast<const f32x4*>(&wtab[i][4 * cc]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (w[j] != 0.f) acc += w[j] * q[j];
             }
         }
         dst[idx] = acc;
@@ -375,7 +391,8 @@ hipError_t trilinear_bwd_separable_launch(const float* dout, float* dsrc, float*
     const int ac = align_corners ? 1 : 0;
     float* t1 = workspace;                                  // [B*D*H][w]
     float* t2 = workspace + (int64_t)B * D * H * w;         // [B*D][h][w]
-    if ((W & 3) == 0 && (reinterpret_cast<uintptr_t>(dout) & 15u) == 0)
+    // window of a coarse index: at most 2 W / w + 4 fine candidates (axis_range) plus 3 of alignment
+    if ((W & 3) == 0 && (reinterpret_cast<uintptr_t>(dout) & 15u) == 0 && w <= kAdjMaxCoarse && 2 * ((W + w - 1) / w) + 7 <= kAdjWin)
         hipLaunchKernelGGL(axis_adjoint_w4_kernel, dim3(grid_for((int64_t)B * D * H * w)), dim3(256), 0, st, dout, t1, (int64_t)B * D * H, W, w, ac);
     else
         hipLaunchKernelGGL(axis_adjoint_kernel, dim3(grid_for((int64_t)B * D * H * w)), dim3(256), 0, st, dout, t1, (int64_t)B * D * H, W, w, (int64_t)1, ac);
