@@ -302,7 +302,11 @@ def main():
     # are bracketed by HIP events here, which perturbs the step by < 1 %; the full per-kernel table comes from an extra,
     # untimed pass below (bracketing all ~300 launches per step costs 40 % at 64^3).  Graph mode: a replay hides the
     # individual launches, so both tables come from eager passes after the timed region.
-    prof = None if (args.no_profile or use_graph) else []
+    # Under DDP the events come from extra steps after the timed region as well: with the nccl process group alive, HIP-event
+    # records inside the step cost 4 ms per 128^3 step (measured: 56.6 ms plain, 57.4 ms DDP without events, 61.1 ms DDP with events -
+    # the process group's watchdog threads contend for the runtime's event lock), which would be charged to every N > 1 point of a
+    # scaling curve but not to its N = 1 point.
+    prof = None if (args.no_profile or use_graph or distributed) else []
     ops.PROFILE, ops.PROFILE_ONLY = prof, ATTN_KERNELS
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -321,15 +325,16 @@ def main():
         rank_ms = [1e3 * x.item() / args.steps for x in every]
         elapsed = max(x.item() for x in every)               # the slowest rank's clock is the job's
     roofline_note = f"the {args.steps} timed steps (HIP events on the launch stream)"
-    if use_graph and not args.no_profile:
+    if (use_graph or distributed) and not args.no_profile:
         prof = []
         ops.PROFILE, ops.PROFILE_ONLY = prof, ATTN_KERNELS
-        for _ in range(min(args.steps, 5)):
+        for _ in range(min(args.steps, 5)):      # every rank runs them: the steps contain DDP's collectives
             eager_step()
         torch.cuda.synchronize()
         ops.PROFILE, ops.PROFILE_ONLY = None, None
         roofline_note = (f"{min(args.steps, 5)} eager steps after the timed region (HIP events on the launch stream; the timed region "
-                         "replays a hipGraph, which hides individual launches)")
+                         + ("replays a hipGraph, which hides individual launches)" if use_graph else
+                            "runs under DDP, where event records inside the step perturb it by 7 %)"))
     full = None
     if prof is not None and rank == 0 and world == 1:
         full = []
@@ -383,7 +388,7 @@ def main():
                                "launches": n, "avg_launch_ms": 1e3 * tsec / n,
                                "algorithmic_flops_per_launch": work / n}
             out["roofline"]["measured_over"] = roofline_note
-            share_src, share_steps = (full, min(args.steps, 3)) if full else (prof, min(args.steps, 5) if use_graph else args.steps)
+            share_src, share_steps = (full, min(args.steps, 3)) if full else (prof, min(args.steps, 5) if (use_graph or distributed) else args.steps)
             agg2 = {}
             for name, work, s_ev, e_ev in share_src:
                 a = agg2.setdefault(name, [0.0, 0.0, 0])

@@ -1725,7 +1725,7 @@ def test_bench_runs_the_ddp_path_over_rccl_on_one_gpu():
     DDP bucket views and all-reduce hooks over the HIP autograd Functions, barrier + max-over-ranks timing - so that the first
     RCCL initialisation does not happen on the driver's 8-GPU run (reference: direct_regression/train_direct_4gpu.py:25-37, :146).
     A world-size-1 all-reduce moves no data over xGMI: the step time must stay within 3 % of the plain single-GPU run."""
-    common = ["--gpus", "1", "--steps", "20", "--warmup", "3", "--no-cpu-baseline", "--no-extra", "--no-profile"]
+    common = ["--gpus", "1", "--steps", "20", "--warmup", "3", "--no-cpu-baseline", "--no-extra"]      # profiling on, as the driver runs it
     # alternating runs, best of two each: run-to-run spread of a 20-step measurement on one box is ~2 % (clock / placement)
     runs = [_run_bench(common + (["--ddp"] if i % 2 == 0 else [])) for i in range(4)]
     ddp = min(runs[0::2], key=lambda d: d["ms_per_step"])
@@ -1733,6 +1733,7 @@ def test_bench_runs_the_ddp_path_over_rccl_on_one_gpu():
     assert ddp["dist_backend"] == "nccl" and ddp["rccl_ranks"] == 1 and ddp["nccl_version"], ddp
     assert ddp["ddp"]["gradient_as_bucket_view"] and ddp["n_gpus"] == 1
     assert "dist_backend" not in plain
+    assert "after the timed region" in ddp["roofline"]["measured_over"] and "timed steps" in plain["roofline"]["measured_over"]
     rel = abs(ddp["ms_per_step"] - plain["ms_per_step"]) / plain["ms_per_step"]
     _note("ddp_vs_plain_ms_per_step", rel, 0.03)
     assert rel < 0.03, (plain["ms_per_step"], ddp["ms_per_step"])
