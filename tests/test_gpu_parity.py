@@ -1745,8 +1745,9 @@ def test_bench_captures_the_ddp_step_with_its_rccl_all_reduce_in_a_hipgraph():
     """The launch-bound 64^3 step under DDP as ONE hipGraph (static_graph DDP, >= 11 eager warm-up iterations, RCCL collectives
     recorded into the capture): replays must train (finite loss) at about the speed of the single-GPU graph."""
     common = ["--gpus", "1", "--workload", "direct64", "--steps", "20", "--warmup", "3", "--no-cpu-baseline", "--no-extra", "--no-profile"]
-    plain = _run_bench(common)
-    ddp = _run_bench(common + ["--ddp"])
+    runs = [_run_bench(common + (["--ddp"] if i % 2 == 0 else [])) for i in range(4)]      # alternating, best of two each
+    ddp = min(runs[0::2], key=lambda d: d["ms_per_step"])
+    plain = min(runs[1::2], key=lambda d: d["ms_per_step"])
     assert plain["config"]["launch"].startswith("hipGraph") and ddp["config"]["launch"].startswith("hipGraph")
     assert ddp["dist_backend"] == "nccl" and ddp["ddp"]["captured_in_hipgraph"] and ddp["ddp"]["static_graph"]
     assert math.isfinite(ddp["config"]["loss"])
