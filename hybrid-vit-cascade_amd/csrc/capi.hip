@@ -399,6 +399,52 @@ int hvc_im2col(const void* src, void* col, int B, int C, int SD, int SH, int SW,
     return hip_result(hvc::im2col_launch(g, src, col, dtype == HVC_BF16, (hipStream_t)stream), "im2col");
 }
 
+int hvc_conv_c1_fwd(const void* x, const void* w2d, const float* bias, void* y, int B, int SD, int SH, int SW, int Cout, int stride,
+                    void* stream) {
+    if (!x || !w2d || !y) return fail(HVC_E_BADARG, "conv_c1_fwd: null operand");
+    if (B < 1 || SD < 1 || SH < 1 || SW < 1) return fail(HVC_E_BADARG, "conv_c1_fwd: empty volume");
+    if (!hvc::conv_c1_supported(Cout, stride)) return fail(HVC_E_UNSUPPORTED, "conv_c1_fwd: Cout must be 32 or 64, stride 1 or 2 (use im2col + gemm)");
+    if (!aligned16(w2d) || !aligned16(y)) return fail(HVC_E_BADARG, "conv_c1_fwd: w2d and y must be 16-byte aligned");
+    hvc::ConvC1Args a{};
+    a.x = x; a.w2d = w2d; a.bias = bias; a.y = y; a.B = B; a.SD = SD; a.SH = SH; a.SW = SW; a.Cout = Cout; a.stride = stride;
+    return hip_result(hvc::conv_c1_fwd_launch(a, (hipStream_t)stream), "conv_c1_fwd");
+}
+
+int64_t hvc_conv_c1_dw_workspace(int B, int SD, int SH, int SW, int Cout, int stride) {
+    if (B < 1 || SD < 1 || SH < 1 || SW < 1 || !hvc::conv_c1_supported(Cout, stride)) return -1;
+    return (int64_t)hvc::conv_c1_dw_parts(B, SD, SH, SW, stride) * Cout * 32;
+}
+
+int hvc_conv_c1_dw(const void* x, const void* dy, float* dw, float* workspace, int B, int SD, int SH, int SW, int Cout, int stride,
+                   void* stream) {
+    if (!x || !dy || !dw || !workspace) return fail(HVC_E_BADARG, "conv_c1_dw: null operand");
+    if (B < 1 || SD < 1 || SH < 1 || SW < 1) return fail(HVC_E_BADARG, "conv_c1_dw: empty volume");
+    if (!hvc::conv_c1_supported(Cout, stride)) return fail(HVC_E_UNSUPPORTED, "conv_c1_dw: Cout must be 32 or 64, stride 1 or 2 (use im2col + gemm)");
+    if (!aligned16(dy)) return fail(HVC_E_BADARG, "conv_c1_dw: dy must be 16-byte aligned");
+    hvc::ConvC1Args a{};
+    a.x = x; a.dy = dy; a.workspace = workspace; a.B = B; a.SD = SD; a.SH = SH; a.SW = SW; a.Cout = Cout; a.stride = stride;
+    return hip_result(hvc::conv_c1_dw_launch(a, dw, (hipStream_t)stream), "conv_c1_dw");
+}
+
+int hvc_conv_o1_fwd(const void* x, const void* w, const float* bias, void* y, int64_t M, int C, void* stream) {
+    if (!x || !w || !y || M < 1) return fail(HVC_E_BADARG, "conv_o1_fwd: bad operand");
+    if (!hvc::conv_o1_supported(C)) return fail(HVC_E_UNSUPPORTED, "conv_o1_fwd: C must be 8, 16, 32, 64 or 128 (use conv_gemm)");
+    if (!aligned16(x) || !aligned16(w)) return fail(HVC_E_BADARG, "conv_o1_fwd: x and w must be 16-byte aligned");
+    return hip_result(hvc::conv_o1_fwd_launch(x, w, bias, y, M, C, (hipStream_t)stream), "conv_o1_fwd");
+}
+
+int64_t hvc_conv_o1_bwd_workspace(int64_t M, int C) {
+    if (M < 1 || !hvc::conv_o1_supported(C)) return -1;
+    return (int64_t)hvc::conv_o1_bwd_blocks(M, C) * (C + 1);
+}
+
+int hvc_conv_o1_bwd(const void* x, const void* dy, const void* w, void* dx, float* dwb, float* workspace, int64_t M, int C, void* stream) {
+    if (!x || !dy || !w || !dwb || !workspace || M < 1) return fail(HVC_E_BADARG, "conv_o1_bwd: bad operand");
+    if (!hvc::conv_o1_supported(C)) return fail(HVC_E_UNSUPPORTED, "conv_o1_bwd: C must be 8, 16, 32, 64 or 128 (use gemm + col2im)");
+    if (!aligned16(x) || !aligned16(w) || (dx && !aligned16(dx))) return fail(HVC_E_BADARG, "conv_o1_bwd: x, w and dx must be 16-byte aligned");
+    return hip_result(hvc::conv_o1_bwd_launch(x, dy, w, dx, dwb, workspace, M, C, (hipStream_t)stream), "conv_o1_bwd");
+}
+
 int hvc_conv_gemm(int mode, const void* src, const void* other, void* out, int B, int C, int SD, int SH, int SW,
                   int KD, int KH, int KW, int stride, int PD, int PH, int PW, int flip, int N, int64_t ld_other, int64_t ld_out,
                   const float* bias, const float* residual, int64_t ldr, int residual_rows,

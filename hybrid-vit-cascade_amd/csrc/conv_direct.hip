@@ -1,0 +1,415 @@
+// Single-channel convolutions of the cascade glue, written as streaming kernels (HBM-bound: one side of each is a 1-channel volume,
+// the other a 32- / 64-channel one):
+//   direct_regression/progressive_cascade/model_progressive.py:171,240,260   Conv3d(1 -> 32 | 64, k3, p1)      upsample_from_* / detail_enhancer[0]
+//   models/hybrid_vit_backbone.py:199                                         Conv3d(1 -> C/4, k3, s2, p1)      first voxel-embed layer of the direct model
+//   direct_regression/progressive_cascade/model_progressive.py:266           Conv3d(32 -> 1, k1)               detail_enhancer[-1]
+// Through im2col + GEMM (spatial.hip, gemm.hip) the Cin = 1 layers wrote and re-read a [voxels][32] patch matrix as large as their own
+// output (1 GiB at 256^3) and kept it for the backward; the Cout = 1 layer ran a 128-wide MFMA tile for one output column and its input
+// gradient went through a [voxels][32] dcol matrix and col2im.  Here:
+//   * conv_c1_fwd : a workgroup stages the halo of a 4 x 8 x 32 output block of the 1-channel volume in LDS (4 KB); each wavefront takes rows
+//                   of 32 output voxels, gathers their 27 taps (padded to 32) from the halo into an MFMA B operand and multiplies by the
+//                   [Cout][32] weight fragment held in registers (two 32x32x16 MFMAs per 32 output channels); the tile goes through a
+//                   wavefront-private LDS stage so that the channels-last stores are 16 bytes per lane, 1 - 2 KiB contiguous per row.
+//   * conv_c1_dw  : the same halo and tap gather, now as the B operand of dW[co][tap] = sum_voxels dy[voxel][co] patch[voxel][tap]; dy rows
+//                   are streamed once (the only HBM traffic that matters), transposed through LDS (ds_read_b64_tr_b16).  Tap 27 of the
+//                   padded patch is the constant 1, so column 27 of the result is the bias gradient.  Per-wavefront fp32 partials, summed
+//                   in a fixed order by a second kernel (deterministic, as the split-K weight gradients of gemm.hip).
+//   * conv_1x1_o1_fwd / _bwd : row dot products / outer products, 16 bytes per lane.
+#include "hvc_common.hip.h"
+#include "hvc_kernels.h"
+
+namespace hvc {
+namespace {
+
+constexpr int kTZ = 4, kTY = 8, kTX = 32;     // output voxels per workgroup: 32 rows (4 x 8) of 32
+constexpr int kTaps = 27, kTapPad = 32;
+
+template <int STRIDE> struct Halo {
+    static constexpr int HZ = STRIDE * (kTZ - 1) + 3, HY = STRIDE * (kTY - 1) + 3, HX = STRIDE * (kTX - 1) + 3;
+    static constexpr int HXP = (HX + 1) & ~1;
+    static constexpr int N = HZ * HY * HXP;
+    static constexpr int tap_off(int t) { return ((t / 9) * HY + (t / 3) % 3) * HXP + t % 3; }      // t = kd * 9 + kh * 3 + kw
+};
+
+struct TileId { int b, z0, y0, x0; };
+
+__device__ __forceinline__ TileId tile_of(const ConvC1Args& a, int t) {
+    TileId id;
+    id.x0 = (t % a.tiles_x) * kTX; t /= a.tiles_x;
+    id.y0 = (t % a.tiles_y) * kTY; t /= a.tiles_y;
+    id.z0 = (t % a.tiles_z) * kTZ;
+    id.b = t / a.tiles_z;
+    return id;
+}
+
+// the input halo of one output block -> LDS (zeros outside the volume: the layer's zero padding)
+template <int STRIDE>
+__device__ __forceinline__ void load_halo(const ConvC1Args& a, const TileId& id, bf16* halo, int tid) {
+    using H = Halo<STRIDE>;
+    const bf16* xb = reinterpret_cast<const bf16*>(a.x) + (int64_t)id.b * a.SD * a.SH * a.SW;
+    const int sz0 = id.z0 * STRIDE - 1, sy0 = id.y0 * STRIDE - 1, sx0 = id.x0 * STRIDE - 1;
+    for (int e = tid; e < H::N; e += 256) {
+        const int hx = e % H::HXP, r = e / H::HXP, hy = r % H::HY, hz = r / H::HY;
+        const int sz = sz0 + hz, sy = sy0 + hy, sx = sx0 + hx;
+        const bool ok = sz >= 0 && sz < a.SD && sy >= 0 && sy < a.SH && sx >= 0 && sx < a.SW;
+        bf16 v = (bf16)0.f;
+        if (ok) v = xb[((int64_t)sz * a.SH + sy) * a.SW + sx];
+        halo[e] = v;
+    }
+}
+
+__device__ __forceinline__ uint32_t pack2(bf16 lo, bf16 hi) {
+    return (uint32_t)__builtin_bit_cast(uint16_t, lo) | ((uint32_t)__builtin_bit_cast(uint16_t, hi) << 16);
+}
+__device__ __forceinline__ bf16x8 from_words(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3) {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    return __builtin_bit_cast(bf16x8, (u32x4){w0, w1, w2, w3});
+}
+
+// ---- forward ----------------------------------------------------------------------------------------------------------------
+template <int STRIDE, int NT>
+__global__ __launch_bounds__(256) void conv_c1_fwd_kernel(const ConvC1Args a) {
+    using H = Halo<STRIDE>;
+    constexpr int ROWB = 64 * NT + 16;                      // bytes per voxel row of the store stage (16-byte aligned, off the bank period)
+    __shared__ __attribute__((aligned(16))) bf16 halo[H::N];
+    __shared__ __attribute__((aligned(16))) char stage_all[4 * kTX * ROWB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+    const TileId id = tile_of(a, blockIdx.x);
+    load_halo<STRIDE>(a, id, halo, tid);
+
+    // weight fragments (A operand: lane <-> output channel, k <-> tap) and the bias of this lane's accumulator rows
+    const bf16* w = reinterpret_cast<const bf16*>(a.w2d);
+    bf16x8 wf[NT][2];
+    float bs[NT][16];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) wf[nt][s] = *reinterpret_cast<const bf16x8*>(w + (size_t)(32 * nt + r) * kTapPad + 16 * s + 8 * h);
+        if (h) {                    // taps 27..31 do not exist: elements 3..7 of the upper half of k-step 1
+#pragma unroll
+            for (int j = 3; j < 8; ++j) wf[nt][1][j] = (bf16)0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) bs[nt][i] = a.bias ? a.bias[32 * nt + acc_row(i, h)] : 0.f;
+    }
+    // per-lane halo offsets of this lane's 16 taps (k-step s, element j <-> tap 16 s + 8 h + j), in elements, relative to the row's origin
+    int toff[2][8];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int t0 = 16 * s + j, t1 = 16 * s + 8 + j;
+            const int o1 = t1 < kTaps ? H::tap_off(t1) : 0;
+            toff[s][j] = (h ? o1 : H::tap_off(t0)) + r * STRIDE;
+        }
+    const uint32_t m23 = h ? 0x0000ffffu : 0xffffffffu, m47 = h ? 0u : 0xffffffffu;
+    char* stage = stage_all + wave * (kTX * ROWB);
+    __syncthreads();
+
+    bf16* yb = reinterpret_cast<bf16*>(a.y);
+#pragma unroll 2
+    for (int i = 0; i < 8; ++i) {
+        const int row = wave * 8 + i, z = row / kTY, yy = row % kTY;
+        const int oz = id.z0 + z, oy = id.y0 + yy;
+        if (oz >= a.OD || oy >= a.OH) continue;                                  // wave-uniform
+        const bf16* hp = halo + ((z * STRIDE) * H::HY + yy * STRIDE) * H::HXP;
+        uint32_t pw[2][4];
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int j = 0; j < 8; j += 2) pw[s][j >> 1] = pack2(hp[toff[s][j]], hp[toff[s][j + 1]]);
+        pw[1][1] &= m23; pw[1][2] &= m47; pw[1][3] &= m47;
+        const bf16x8 p0 = from_words(pw[0][0], pw[0][1], pw[0][2], pw[0][3]), p1 = from_words(pw[1][0], pw[1][1], pw[1][2], pw[1][3]);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            f32x16 acc;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] = bs[nt][e];
+            acc = mfma32(wf[nt][0], p0, acc);
+            acc = mfma32(wf[nt][1], p1, acc);
+            // rows = output channel (registers), column = voxel (lane): four consecutive channels per register group
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const uint32_t lo = pack2(f2bf(acc[4 * g]), f2bf(acc[4 * g + 1])), hi = pack2(f2bf(acc[4 * g + 2]), f2bf(acc[4 * g + 3]));
+                typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+                *reinterpret_cast<u32x2*>(stage + r * ROWB + (32 * nt + 8 * g + 4 * h) * 2) = (u32x2){lo, hi};
+            }
+        }
+        // 32 voxels x (64 NT) bytes, contiguous in the channels-last output: 16 bytes per lane
+        bf16* yrow = yb + ((((int64_t)id.b * a.OD + oz) * a.OH + oy) * a.OW + id.x0) * a.Cout;
+#pragma unroll
+        for (int k = 0; k < 2 * NT; ++k) {
+            const int c = lane + 64 * k, vox = c / (4 * NT), part = c % (4 * NT);
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(stage + vox * ROWB + part * 16);
+            if (id.x0 + vox < a.OW) *reinterpret_cast<bf16x8*>(yrow + vox * a.Cout + part * 8) = v;
+        }
+    }
+}
+
+// ---- weight (and bias) gradient ------------------------------------------------------------------------------------------------
+template <int STRIDE, int NT>
+__global__ __launch_bounds__(256) void conv_c1_dw_kernel(const ConvC1Args a) {
+    using H = Halo<STRIDE>;
+    constexpr int CW = 32 * NT;                              // dy tile width (output channels)
+    __shared__ __attribute__((aligned(16))) bf16 halo[H::N];
+    __shared__ __attribute__((aligned(16))) bf16 dyt_all[4 * kTX * CW];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+    bf16* dyt = dyt_all + wave * (kTX * CW);
+    // B operand: lane <-> tap r, k <-> voxel 16 s + 8 h + j of the row
+    const bool one = r == kTaps;                              // tap 27: the constant 1 (its dW column is the bias gradient)
+    const int tbase = (r < kTaps ? H::tap_off(r) : 0) + 8 * h * STRIDE;
+    f32x16 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[nt][e] = 0.f;
+    const bf16* dyb = reinterpret_cast<const bf16*>(a.dy);
+    const uint32_t ones = 0x3f803f80u;
+
+    for (int t = blockIdx.x; t < a.ntiles; t += gridDim.x) {
+        const TileId id = tile_of(a, t);
+        __syncthreads();                                      // the previous tile's halo has been read
+        load_halo<STRIDE>(a, id, halo, tid);
+        __syncthreads();
+        // dy rows of the wavefront's 8 output rows, one row ahead in registers (two rows in flight per wavefront)
+        auto load_row = [&](int i, bf16x8 (&v)[2 * NT]) {
+            const int row = wave * 8 + i, oz = id.z0 + row / kTY, oy = id.y0 + row % kTY;
+            const bool in = i < 8 && oz < a.OD && oy < a.OH;
+            const bf16* drow = dyb + ((((int64_t)id.b * a.OD + (in ? oz : 0)) * a.OH + (in ? oy : 0)) * a.OW + id.x0) * a.Cout;
+#pragma unroll
+            for (int k = 0; k < 2 * NT; ++k) {
+                const int c = lane + 64 * k, vox = c / (4 * NT), part = c % (4 * NT);
+                v[k] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                if (in && id.x0 + vox < a.OW) v[k] = *reinterpret_cast<const bf16x8*>(drow + vox * a.Cout + part * 8);      // zeros past the end of the row
+            }
+        };
+        bf16x8 cur[2 * NT], nxt[2 * NT];
+        load_row(0, cur);
+#pragma unroll 1
+        for (int i = 0; i < 8; ++i) {
+            load_row(i + 1, nxt);
+            const int row = wave * 8 + i, z = row / kTY, yy = row % kTY;
+            // -> LDS tile [voxel][co] (rows outside the volume are zeros: they add nothing)
+#pragma unroll
+            for (int k = 0; k < 2 * NT; ++k) {
+                const int c = lane + 64 * k;
+                tile_store<CW>(dyt, c / (4 * NT), c % (4 * NT), cur[k]);
+            }
+            const bf16* hp = halo + ((z * STRIDE) * H::HY + yy * STRIDE) * H::HXP + tbase;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                uint32_t pw[4];
+#pragma unroll
+                for (int j = 0; j < 8; j += 2) pw[j >> 1] = one ? ones : pack2(hp[(16 * s + j) * STRIDE], hp[(16 * s + j + 1) * STRIDE]);
+                const bf16x8 pf = from_words(pw[0], pw[1], pw[2], pw[3]);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const bf16x8 df = tr_frag<CW, false>(dyt, 16 * s, 32 * nt, lane);      // lane <-> co, k <-> voxel
+                    acc[nt] = mfma32(df, pf, acc[nt]);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 2 * NT; ++k) cur[k] = nxt[k];
+        }
+    }
+    // rows = co (registers), column = tap (lane)
+    float* ws = a.workspace + ((size_t)blockIdx.x * 4 + wave) * (a.Cout * kTapPad);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) ws[(32 * nt + acc_row(e, h)) * kTapPad + r] = acc[nt][e];
+}
+
+// dw[e] = sum over the partials, fixed order: a block takes 32 consecutive outputs, its 256 threads = 32 outputs x 8 row groups
+__global__ __launch_bounds__(256) void conv_c1_dw_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int n, int parts) {
+    __shared__ float red[8][32];
+    const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int e = blockIdx.x * 32 + cl;
+    float s0 = 0.f, s1 = 0.f;
+    if (e < n) {
+        int p = rg;
+        for (; p + 8 < parts; p += 16) { s0 += ws[(size_t)p * n + e]; s1 += ws[(size_t)(p + 8) * n + e]; }
+        if (p < parts) s0 += ws[(size_t)p * n + e];
+    }
+    red[rg][cl] = s0 + s1;
+    __syncthreads();
+    if (rg == 0 && e < n) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += red[k][cl];
+        dw[e] = s;
+    }
+}
+
+// ---- 1 x 1 x 1, one output channel ---------------------------------------------------------------------------------------------------
+// y[m] = bias + sum_c x[m][c] w[c]: CH = C / 8 lanes per row, 16 bytes each
+template <int CH>
+__global__ __launch_bounds__(256) void conv_o1_fwd_kernel(const bf16* __restrict__ x, const bf16* __restrict__ w, const float* __restrict__ bias,
+                                                          bf16* __restrict__ y, int64_t M) {
+    const int part = threadIdx.x % CH;
+    float wv[8];
+    {
+        const bf16x8 wc = *reinterpret_cast<const bf16x8*>(w + part * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) wv[j] = bf2f(wc[j]);
+    }
+    const float b0 = bias ? bias[0] : 0.f;
+    const int64_t total = M * CH, step = (int64_t)gridDim.x * 256;
+    constexpr int U = 4;
+    for (int64_t base = (int64_t)blockIdx.x * 256 + threadIdx.x; base < total; base += step * U) {
+        bf16x8 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t c = base + u * step;
+            v[u] = c < total ? *reinterpret_cast<const bf16x8*>(x + c * 8) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s = __builtin_fmaf(bf2f(v[u][j]), wv[j], s);
+#pragma unroll
+            for (int o = 1; o < CH; o <<= 1) s += __shfl_xor(s, o);
+            const int64_t c = base + u * step;
+            if (part == 0 && c < total) y[c / CH] = f2bf(s + b0);
+        }
+    }
+}
+
+// dx[m][c] = dy[m] w[c];  partial dw[c] = sum_m dy[m] x[m][c], db = sum_m dy[m] per workgroup (fixed-order second pass)
+template <int CH>
+__global__ __launch_bounds__(256) void conv_o1_bwd_kernel(const bf16* __restrict__ x, const bf16* __restrict__ dy, const bf16* __restrict__ w,
+                                                          bf16* __restrict__ dx, float* __restrict__ ws, int64_t M) {
+    __shared__ float red[256][9];
+    const int part = threadIdx.x % CH;
+    float wv[8], dw[8], db = 0.f;
+    {
+        const bf16x8 wc = *reinterpret_cast<const bf16x8*>(w + part * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { wv[j] = bf2f(wc[j]); dw[j] = 0.f; }
+    }
+    const int64_t total = M * CH, step = (int64_t)gridDim.x * 256;
+    constexpr int U = 4;
+    for (int64_t base = (int64_t)blockIdx.x * 256 + threadIdx.x; base < total; base += step * U) {
+        bf16x8 v[U];
+        float g[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t c = base + u * step;
+            const bool ok = c < total;
+            v[u] = ok ? *reinterpret_cast<const bf16x8*>(x + c * 8) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            g[u] = ok ? bf2f(dy[c / CH]) : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t c = base + u * step;
+            bf16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                dw[j] = __builtin_fmaf(g[u], bf2f(v[u][j]), dw[j]);
+                o[j] = f2bf(g[u] * wv[j]);
+            }
+            if (part == 0) db += g[u];
+            if (dx && c < total) *reinterpret_cast<bf16x8*>(dx + c * 8) = o;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[threadIdx.x][j] = dw[j];
+    red[threadIdx.x][8] = db;
+    __syncthreads();
+    // threads 0 .. 8 CH: one output each, summed over the 256 / CH threads of its part in a fixed order
+    if (threadIdx.x < 8 * CH + 1) {
+        const int o = threadIdx.x;
+        const int p = o < 8 * CH ? o / 8 : 0, j = o < 8 * CH ? o % 8 : 8;
+        float s = 0.f;
+        for (int t = p; t < 256; t += CH) s += red[t][j];
+        ws[(size_t)blockIdx.x * (8 * CH + 1) + o] = s;
+    }
+}
+
+template <typename K>
+void launch_c1(K kernel, int grid, const ConvC1Args& a, hipStream_t st) { hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), 0, st, a); }
+
+}  // namespace
+
+bool conv_c1_supported(int Cout, int stride) { return (Cout == 32 || Cout == 64) && (stride == 1 || stride == 2); }
+
+static void fill_tiles(ConvC1Args& a) {
+    a.OD = (a.SD - 1) / a.stride + 1; a.OH = (a.SH - 1) / a.stride + 1; a.OW = (a.SW - 1) / a.stride + 1;      // k3 p1
+    a.tiles_x = (a.OW + kTX - 1) / kTX; a.tiles_y = (a.OH + kTY - 1) / kTY; a.tiles_z = (a.OD + kTZ - 1) / kTZ;
+    a.ntiles = a.B * a.tiles_z * a.tiles_y * a.tiles_x;
+}
+
+int conv_c1_dw_parts(int B, int SD, int SH, int SW, int stride) {
+    ConvC1Args a{};
+    a.B = B; a.SD = SD; a.SH = SH; a.SW = SW; a.stride = stride;
+    fill_tiles(a);
+    const int grid = a.ntiles < 4 * cu_count() ? a.ntiles : 4 * cu_count();
+    return grid * 4;
+}
+
+hipError_t conv_c1_fwd_launch(ConvC1Args a, hipStream_t st) {
+    fill_tiles(a);
+    if (!conv_c1_supported(a.Cout, a.stride) || (int64_t)a.B * a.tiles_z * a.tiles_y * a.tiles_x > 0x7fffffff) return hipErrorInvalidValue;
+    if (a.stride == 1) { if (a.Cout == 32) launch_c1(conv_c1_fwd_kernel<1, 1>, a.ntiles, a, st); else launch_c1(conv_c1_fwd_kernel<1, 2>, a.ntiles, a, st); }
+    else { if (a.Cout == 32) launch_c1(conv_c1_fwd_kernel<2, 1>, a.ntiles, a, st); else launch_c1(conv_c1_fwd_kernel<2, 2>, a.ntiles, a, st); }
+    return hipGetLastError();
+}
+
+hipError_t conv_c1_dw_launch(ConvC1Args a, float* dw, hipStream_t st) {
+    fill_tiles(a);
+    if (!conv_c1_supported(a.Cout, a.stride)) return hipErrorInvalidValue;
+    const int parts = conv_c1_dw_parts(a.B, a.SD, a.SH, a.SW, a.stride), grid = parts / 4;
+    if (a.stride == 1) { if (a.Cout == 32) launch_c1(conv_c1_dw_kernel<1, 1>, grid, a, st); else launch_c1(conv_c1_dw_kernel<1, 2>, grid, a, st); }
+    else { if (a.Cout == 32) launch_c1(conv_c1_dw_kernel<2, 1>, grid, a, st); else launch_c1(conv_c1_dw_kernel<2, 2>, grid, a, st); }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    const int n = a.Cout * kTapPad;
+    hipLaunchKernelGGL(conv_c1_dw_reduce_kernel, dim3((n + 31) / 32), dim3(256), 0, st, a.workspace, dw, n, parts);
+    return hipGetLastError();
+}
+
+bool conv_o1_supported(int C) { return C == 8 || C == 16 || C == 32 || C == 64 || C == 128; }
+
+int conv_o1_bwd_blocks(int64_t M, int C) {
+    const int64_t want = (M * (C / 8) + 256 * 4 - 1) / (256 * 4);
+    const int cap = 8 * cu_count();
+    return (int)(want < cap ? (want < 1 ? 1 : want) : cap);
+}
+
+hipError_t conv_o1_fwd_launch(const void* x, const void* w, const float* bias, void* y, int64_t M, int C, hipStream_t st) {
+    if (!conv_o1_supported(C)) return hipErrorInvalidValue;
+    const int64_t want = (M * (C / 8) + 256 * 4 - 1) / (256 * 4);
+    const int grid = (int)(want < 16 * (int64_t)cu_count() ? (want < 1 ? 1 : want) : 16 * cu_count());
+    const bf16 *xp = (const bf16*)x, *wp = (const bf16*)w;
+    bf16* yp = (bf16*)y;
+    switch (C / 8) {
+        case 1: hipLaunchKernelGGL(conv_o1_fwd_kernel<1>, dim3(grid), dim3(256), 0, st, xp, wp, bias, yp, M); break;
+        case 2: hipLaunchKernelGGL(conv_o1_fwd_kernel<2>, dim3(grid), dim3(256), 0, st, xp, wp, bias, yp, M); break;
+        case 4: hipLaunchKernelGGL(conv_o1_fwd_kernel<4>, dim3(grid), dim3(256), 0, st, xp, wp, bias, yp, M); break;
+        case 8: hipLaunchKernelGGL(conv_o1_fwd_kernel<8>, dim3(grid), dim3(256), 0, st, xp, wp, bias, yp, M); break;
+        default: hipLaunchKernelGGL(conv_o1_fwd_kernel<16>, dim3(grid), dim3(256), 0, st, xp, wp, bias, yp, M); break;
+    }
+    return hipGetLastError();
+}
+
+hipError_t conv_o1_bwd_launch(const void* x, const void* dy, const void* w, void* dx, float* dwb, float* workspace, int64_t M, int C, hipStream_t st) {
+    if (!conv_o1_supported(C)) return hipErrorInvalidValue;
+    const int grid = conv_o1_bwd_blocks(M, C);
+    const bf16 *xp = (const bf16*)x, *dyp = (const bf16*)dy, *wp = (const bf16*)w;
+    bf16* dxp = (bf16*)dx;
+    switch (C / 8) {
+        case 1: hipLaunchKernelGGL(conv_o1_bwd_kernel<1>, dim3(grid), dim3(256), 0, st, xp, dyp, wp, dxp, workspace, M); break;
+        case 2: hipLaunchKernelGGL(conv_o1_bwd_kernel<2>, dim3(grid), dim3(256), 0, st, xp, dyp, wp, dxp, workspace, M); break;
+        case 4: hipLaunchKernelGGL(conv_o1_bwd_kernel<4>, dim3(grid), dim3(256), 0, st, xp, dyp, wp, dxp, workspace, M); break;
+        case 8: hipLaunchKernelGGL(conv_o1_bwd_kernel<8>, dim3(grid), dim3(256), 0, st, xp, dyp, wp, dxp, workspace, M); break;
+        default: hipLaunchKernelGGL(conv_o1_bwd_kernel<16>, dim3(grid), dim3(256), 0, st, xp, dyp, wp, dxp, workspace, M); break;
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    const int n = C + 1;
+    hipLaunchKernelGGL(conv_c1_dw_reduce_kernel, dim3((n + 31) / 32), dim3(256), 0, st, workspace, dwb, n, grid);
+    return hipGetLastError();
+}
+
+}  // namespace hvc

@@ -207,6 +207,28 @@ int64_t trilinear_bwd_workspace_floats(int B, int d, int h, int w, int D, int H,
 hipError_t trilinear_bwd_separable_launch(const float* dout, float* dsrc, float* workspace, int B, int d, int h, int w, int D, int H, int W,
                                           bool align_corners, hipStream_t st);
 
+// Single-channel convolutions as streaming kernels (conv_direct.hip): Conv3d(1 -> 32 | 64, k3, p1, stride 1 | 2) forward and weight / bias
+// gradient, Conv3d(C -> 1, k1) forward and backward.  bf16 operands, channels-last.
+struct ConvC1Args {
+    const void* x;           // [B][SD][SH][SW] bf16 (one channel)
+    const void* w2d;         // [Cout][32] bf16: taps 27 .. 31 are padding
+    const float* bias;       // [Cout] or null
+    void* y;                 // [B][OD][OH][OW][Cout] bf16
+    const void* dy;          // the same shape (weight gradient)
+    float* workspace;        // weight gradient: conv_c1_dw_parts() x Cout x 32 floats
+    int B, SD, SH, SW, Cout, stride;
+    int OD, OH, OW, tiles_x, tiles_y, tiles_z, ntiles;      // filled by the launchers
+};
+bool conv_c1_supported(int Cout, int stride);
+int conv_c1_dw_parts(int B, int SD, int SH, int SW, int stride);
+hipError_t conv_c1_fwd_launch(ConvC1Args a, hipStream_t st);
+hipError_t conv_c1_dw_launch(ConvC1Args a, float* dw, hipStream_t st);      // dw: [Cout][32] fp32, column 27 = bias gradient
+bool conv_o1_supported(int C);
+int conv_o1_bwd_blocks(int64_t M, int C);
+hipError_t conv_o1_fwd_launch(const void* x, const void* w, const float* bias, void* y, int64_t M, int C, hipStream_t st);
+// dwb: [C + 1] fp32 = dW, then the bias gradient; workspace: conv_o1_bwd_blocks() x (C + 1) floats; dx may be null
+hipError_t conv_o1_bwd_launch(const void* x, const void* dy, const void* w, void* dx, float* dwb, float* workspace, int64_t M, int C, hipStream_t st);
+
 struct PoolGeom { int N, H, W, C, HP, WP, k, s, p; };
 struct NormArgs {
     const void* x; void* y; const void* dy; void* dx;

@@ -181,41 +181,38 @@ __device__ __forceinline__ float act_grad_f(float z, int act) {
 }
 
 // ---- GroupNorm + SiLU apply ---------------------------------------------------------------------------
+// grid = (blocks, B).  C / 8 divides 256, so a thread's 8 channels (tid % (C / 8)) are the same for every chunk it visits: affine
+// parameters and - when its 8 channels lie in one group - the statistics are fetched once, and the sweep has no division in it
+// (round 4: the flat 64-bit index cost two 64-bit divisions per 16-byte chunk, ~300 instructions; 908 -> ~480 us at 256^3 x 32).
 template <typename T>
 __global__ __launch_bounds__(256) void gn_silu_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, const float* __restrict__ stats,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                           int B, int P, int C, int G, int act) {
-    const int c8n = C / 8, cg = C / G;
-    const int64_t total = (int64_t)B * P * c8n;
-    // a thread keeps its 8 channels for the whole sweep when the grid stride is a multiple of C / 8: affine parameters
-    // are fetched once; when its 8 channels lie in one group (C / G a multiple of 8) so are the statistics' addresses.
-    const bool fixed = ((int64_t)gridDim.x * 256) % c8n == 0;
-    const bool one_group = cg % 8 == 0;
-    float gam[8], bet[8];
-    auto coeffs = [&](int c8) {
+                                                           int P, int C, int G, int act) {
+    const int c8n = C / 8, cg = C / G, b = blockIdx.y;
+    const int c8 = threadIdx.x % c8n;
+    const int64_t total = (int64_t)P * c8n, step = (int64_t)gridDim.x * 256;
+    const T* xb = x + (int64_t)b * P * C;
+    T* yb = y + (int64_t)b * P * C;
+    float gam[8], bet[8], mean[8], rstd[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { gam[j] = gamma[c8 * 8 + j]; bet[j] = beta[c8 * 8 + j]; }
-    };
-    if (fixed) coeffs((int)(((int64_t)blockIdx.x * 256 + threadIdx.x) % c8n));
-    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
-        const int c8 = (int)(idx % c8n);
-        const int b = (int)(idx / ((int64_t)P * c8n));
-        if (!fixed) coeffs(c8);
-        float v[8];
-        load8<T>(x + idx * 8, v);
-        if (one_group) {
-            const int sg = b * G + (c8 * 8) / cg;
-            const float mean = stats[2 * sg], rstd = stats[2 * sg + 1];
+    for (int j = 0; j < 8; ++j) {
+        const int c = c8 * 8 + j, sg = b * G + c / cg;
+        gam[j] = gamma[c]; bet[j] = beta[c];
+        mean[j] = stats[2 * sg]; rstd[j] = stats[2 * sg + 1];
+    }
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += 2 * step) {
+        const bool two = idx + step < total;
+        float v[8], w[8];
+        load8<T>(xb + idx * 8, v);
+        if (two) load8<T>(xb + (idx + step) * 8, w);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = act_f((v[j] - mean) * rstd * gam[j] + bet[j], act);
-        } else {
+        for (int j = 0; j < 8; ++j) v[j] = act_f((v[j] - mean[j]) * rstd[j] * gam[j] + bet[j], act);
+        store8<T>(yb + idx * 8, v);
+        if (two) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int sg = b * G + (c8 * 8 + j) / cg;
-                v[j] = act_f((v[j] - stats[2 * sg]) * stats[2 * sg + 1] * gam[j] + bet[j], act);
-            }
+            for (int j = 0; j < 8; ++j) w[j] = act_f((w[j] - mean[j]) * rstd[j] * gam[j] + bet[j], act);
+            store8<T>(yb + (idx + step) * 8, w);
         }
-        store8<T>(y + idx * 8, v);
     }
 }
 
@@ -292,43 +289,38 @@ __global__ __launch_bounds__(256) void gn_bwd_finish_kernel(const float* __restr
     if (threadIdx.x == 0) { gsum[2 * j] = (float)flat0[0]; gsum[2 * j + 1] = (float)flat1[0]; }
 }
 
+// grid = (blocks, B); a thread keeps its 8 channels, as in gn_silu_fwd_kernel
 template <typename T>
 __global__ __launch_bounds__(256) void gn_silu_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx,
                                                                  const float* __restrict__ stats, const float* __restrict__ gsum,
                                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                                 int B, int P, int C, int G, int act) {
-    const int c8n = C / 8, cg = C / G;
+                                                                 int P, int C, int G, int act) {
+    const int c8n = C / 8, cg = C / G, b = blockIdx.y;
+    const int c8 = threadIdx.x % c8n;
     const float inv_n = 1.f / ((float)P * cg);
-    const int64_t total = (int64_t)B * P * c8n;
-    const bool fixed = ((int64_t)gridDim.x * 256) % c8n == 0;       // see gn_silu_fwd_kernel
-    const bool one_group = cg % 8 == 0;
-    float gam[8], bet[8];
-    auto coeffs = [&](int c8) {
+    const int64_t total = (int64_t)P * c8n, step = (int64_t)gridDim.x * 256;
+    const T* xb = x + (int64_t)b * P * C;
+    const T* db = dy + (int64_t)b * P * C;
+    T* ob = dx + (int64_t)b * P * C;
+    float gam[8], bet[8], mean[8], rstd[8], s0[8], s1[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { gam[j] = gamma[c8 * 8 + j]; bet[j] = beta[c8 * 8 + j]; }
-    };
-    if (fixed) coeffs((int)(((int64_t)blockIdx.x * 256 + threadIdx.x) % c8n));
-    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
-        const int c8 = (int)(idx % c8n);
-        const int b = (int)(idx / ((int64_t)P * c8n));
-        if (!fixed) coeffs(c8);
+    for (int j = 0; j < 8; ++j) {
+        const int c = c8 * 8 + j, sg = b * G + c / cg;
+        gam[j] = gamma[c]; bet[j] = beta[c];
+        mean[j] = stats[2 * sg]; rstd[j] = stats[2 * sg + 1];
+        s0[j] = gsum[2 * sg]; s1[j] = gsum[2 * sg + 1];
+    }
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += step) {
         float xv[8], dv[8], o[8];
-        load8<T>(x + idx * 8, xv);
-        load8<T>(dy + idx * 8, dv);
-        const int sg0 = b * G + (c8 * 8) / cg;
-        const float mean0 = stats[2 * sg0], rstd0 = stats[2 * sg0 + 1], g0 = gsum[2 * sg0], g1 = gsum[2 * sg0 + 1];
+        load8<T>(xb + idx * 8, xv);
+        load8<T>(db + idx * 8, dv);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            float mean = mean0, rstd = rstd0, s0 = g0, s1 = g1;
-            if (!one_group) {
-                const int sg = b * G + (c8 * 8 + j) / cg;
-                mean = stats[2 * sg]; rstd = stats[2 * sg + 1]; s0 = gsum[2 * sg]; s1 = gsum[2 * sg + 1];
-            }
-            const float xh = (xv[j] - mean) * rstd;
+            const float xh = (xv[j] - mean[j]) * rstd[j];
             const float ds = dv[j] * act_grad_f(xh * gam[j] + bet[j], act);
-            o[j] = rstd * (ds * gam[j] - (s0 + xh * s1) * inv_n);
+            o[j] = rstd[j] * (ds * gam[j] - (s0[j] + xh * s1[j]) * inv_n);
         }
-        store8<T>(dx + idx * 8, o);
+        store8<T>(ob + idx * 8, o);
     }
 }
 
@@ -523,13 +515,20 @@ int norm_chunks(int P) {
         else { using T = float; CALL; }          \
     } while (0)
 
+// blocks per sample of the GroupNorm apply kernels: the chip's share of grid_for()'s cap, at least one
+static int apply_blocks(const NormArgs& a) {
+    const int64_t want = ((int64_t)a.P * a.C / 8 + 255) / 256;
+    const int64_t cap = (grid_for((int64_t)1 << 40) + a.B - 1) / a.B;
+    return (int)(want < cap ? (want < 1 ? 1 : want) : (cap < 1 ? 1 : cap));
+}
+
 hipError_t groupnorm_silu_fwd_launch(const NormArgs& a, hipStream_t st) {
     if (a.C % 8 || a.C > kMaxC || 256 % (a.C / 8) || a.C % a.G) return hipErrorInvalidValue;
     const int nch = norm_chunks(a.P);
     HVC_DISPATCH_T(a.is_bf16, hipLaunchKernelGGL(chan_stats_kernel<T>, dim3(nch, a.B), dim3(256), 0, st, (const T*)a.x, a.partial, a.P, a.C, nch));
     hipLaunchKernelGGL(gn_finish_kernel, dim3(a.B * a.G), dim3(256), 0, st, a.partial, a.stats, a.B, a.P, a.C, a.G, nch, a.eps);
-    HVC_DISPATCH_T(a.is_bf16, hipLaunchKernelGGL(gn_silu_fwd_kernel<T>, dim3(grid_for((int64_t)a.B * a.P * a.C / 8)), dim3(256), 0, st,
-                                                 (const T*)a.x, (T*)a.y, a.stats, a.gamma, a.beta, a.B, a.P, a.C, a.G, a.act));
+    HVC_DISPATCH_T(a.is_bf16, hipLaunchKernelGGL(gn_silu_fwd_kernel<T>, dim3(apply_blocks(a), a.B), dim3(256), 0, st,
+                                                 (const T*)a.x, (T*)a.y, a.stats, a.gamma, a.beta, a.P, a.C, a.G, a.act));
     return hipGetLastError();
 }
 
@@ -540,8 +539,8 @@ hipError_t groupnorm_silu_bwd_launch(const NormArgs& a, hipStream_t st) {
                                                  a.stats, a.gamma, a.beta, a.partial, a.P, a.C, a.G, nch, a.act));
     hipLaunchKernelGGL(gn_bwd_finish_kernel, dim3((a.C + 31) / 32 + a.B * a.G), dim3(256), 0, st, a.partial, a.gamma, a.dgamma, a.dbeta,
                        a.gsum, a.B, a.C, a.G, nch);
-    HVC_DISPATCH_T(a.is_bf16, hipLaunchKernelGGL(gn_silu_bwd_apply_kernel<T>, dim3(grid_for((int64_t)a.B * a.P * a.C / 8)), dim3(256), 0, st,
-                                                 (const T*)a.x, (const T*)a.dy, (T*)a.dx, a.stats, a.gsum, a.gamma, a.beta, a.B, a.P, a.C, a.G, a.act));
+    HVC_DISPATCH_T(a.is_bf16, hipLaunchKernelGGL(gn_silu_bwd_apply_kernel<T>, dim3(apply_blocks(a), a.B), dim3(256), 0, st,
+                                                 (const T*)a.x, (const T*)a.dy, (T*)a.dx, a.stats, a.gsum, a.gamma, a.beta, a.P, a.C, a.G, a.act));
     return hipGetLastError();
 }
 

@@ -44,6 +44,12 @@ SIGNATURES = {
     "hvc_cast": (_i, [_p, _p, _i64, _i, _i, _p]),
     "hvc_im2col": (_i, [_p, _p] + [_i] * 13 + [_i64, _i, _p]),
     "hvc_col2im": (_i, [_p, _p] + [_i] * 13 + [_i64, _i, _p]),
+    "hvc_conv_c1_fwd": (_i, [_p, _p, _p, _p] + [_i] * 6 + [_p]),
+    "hvc_conv_c1_dw_workspace": (_i64, [_i] * 6),
+    "hvc_conv_c1_dw": (_i, [_p, _p, _p, _p] + [_i] * 6 + [_p]),
+    "hvc_conv_o1_fwd": (_i, [_p, _p, _p, _p, _i64, _i, _p]),
+    "hvc_conv_o1_bwd_workspace": (_i64, [_i64, _i]),
+    "hvc_conv_o1_bwd": (_i, [_p] * 6 + [_i64, _i, _p]),
     "hvc_conv_gemm": (_i, [_i, _p, _p, _p] + [_i] * 14 + [_i64, _i64, _p, _p, _i64, _i, _p, _i64, _i, _i, _p]),
     "hvc_conv_dx_class_columns": (_i, [_i] * 10 + [_p, _p]),
     "hvc_conv_dx_class": (_i, [_p, _p, _p] + [_i] * 19 + [_i64, _i, _p]),

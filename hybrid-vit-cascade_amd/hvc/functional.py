@@ -577,6 +577,7 @@ def conv_weight_classes(weight: torch.Tensor, dtype: torch.dtype, geom) -> torch
 
 
 CONV_IMPLICIT = True          # C % 8 == 0 convolutions gather their patches inside the GEMM (no im2col / col2im round trip)
+CONV_DIRECT = True            # Conv3d(1 -> 32 | 64, k3, p1) and Conv3d(C -> 1, k1) in bf16 run as streaming kernels (ops.conv_c1_* / conv_o1_*)
 CONV_SLAB_BYTES = 2 << 30     # patch matrices larger than this are built (and rebuilt in backward) slab by slab along D
 
 
@@ -636,6 +637,25 @@ class ConvFn(torch.autograd.Function):
         esize = 2 if cdt == torch.bfloat16 else 4
         implicit = CONV_IMPLICIT and geom.C % 8 == 0 and not geom.out_depth
         slabbed = not implicit and geom.M * geom.Kp * esize > CONV_SLAB_BYTES
+        # single-channel layers as streaming kernels (csrc/conv_direct.hip): no patch matrix, the 1-channel side is what is saved
+        direct = None
+        if CONV_DIRECT and addvec is None and out_dtype == cdt:
+            if ops.conv_c1_supported(geom, cout, cdt):
+                direct = "c1"
+            elif cout == 1 and geom.taps == 1 and geom.stride == 1 and not any(geom.pad) and ops.conv_o1_supported(geom.C, cdt) and not geom.out_depth:
+                direct = "o1"
+        if direct == "c1":
+            xc = xc.contiguous()
+            y = ops.conv_c1_fwd(xc, w2d, _f32(bias), geom)
+            ctx.save_for_backward(xc, weight)
+            ctx.cfg = (geom, cdt, x.dtype, bias is not None, None, False, direct)
+            return y
+        if direct == "o1":
+            xc = xc.contiguous()
+            y = ops.conv_o1_fwd(xc.view(geom.M, geom.C), w2d.view(-1), _f32(bias)).view(geom.B, *geom.out, 1)
+            ctx.save_for_backward(xc, weight)
+            ctx.cfg = (geom, cdt, x.dtype, bias is not None, None, False, direct)
+            return y
         add = None
         if addvec is not None:
             if slabbed:
@@ -675,6 +695,26 @@ class ConvFn(torch.autograd.Function):
         cout = weight.shape[0]
         taps = geom.taps
         dyc = _as_cdt(dy.reshape(geom.M, cout), cdt)
+        if implicit == "c1":
+            xc = saved
+            dwt, db = ops.conv_c1_dw(xc, dyc.contiguous(), geom) if (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]) else (None, None)
+            dw = dwt.reshape(weight.shape) if ctx.needs_input_grad[1] else None
+            dx = None
+            if ctx.needs_input_grad[0]:
+                dx = _conv_dx_slabs(dyc.view(geom.B, *geom.out, cout), conv_weight_2d(weight, cdt, geom.Kp), geom, cdt)
+                if dx.dtype != xdt:
+                    dx = dx.to(xdt)
+            return dx, dw, (db if has_bias and ctx.needs_input_grad[2] else None), None, None, None, None
+        if implicit == "o1":
+            xc = saved
+            dx, dwv, db = ops.conv_o1_bwd(xc.view(geom.M, geom.C), dyc.contiguous().view(-1), conv_weight_2d(weight, cdt, geom.Kp).view(-1),
+                                          need_dx=ctx.needs_input_grad[0])
+            if dx is not None:
+                dx = dx.view(geom.B, *geom.src, geom.C)
+                if dx.dtype != xdt:
+                    dx = dx.to(xdt)
+            return (dx, dwv.reshape(weight.shape) if ctx.needs_input_grad[1] else None, db.reshape(1) if has_bias and ctx.needs_input_grad[2] else None,
+                    None, None, None, None)
         db = ops.colsum(dyc) if has_bias and ctx.needs_input_grad[2] else None
         w2d = conv_weight_2d(weight, cdt, geom.Kp)
         dw = dx = None

@@ -424,6 +424,73 @@ def col2im(dcol, geom):
     return dx
 
 
+def conv_c1_supported(geom, cout, dtype):
+    """Conv3d(1 -> 32 | 64, k3, p1, stride 1 | 2) on bf16 activations: the layers hvc_conv_c1_* cover."""
+    return (dtype == torch.bfloat16 and geom.C == 1 and geom.kernel == (3, 3, 3) and geom.pad == (1, 1, 1) and geom.stride in (1, 2)
+            and cout in (32, 64) and not geom.out_depth)
+
+
+def conv_c1_fwd(x, w2d, bias, geom):
+    """x: (B, D, H, W[, 1]) bf16 contiguous, w2d: (Cout, 32) bf16 (tap-major, columns 27.. ignored) -> (B, OD, OH, OW, Cout) bf16."""
+    _dev(x, w2d, bias)
+    cout = w2d.shape[0]
+    if not conv_c1_supported(geom, cout, x.dtype) or x.numel() != geom.B * geom.src[0] * geom.src[1] * geom.src[2] or not x.is_contiguous():
+        raise ValueError("conv_c1_fwd: contiguous bf16 one-channel volume and a k3 p1 geometry with 32 / 64 output channels expected")
+    if w2d.shape != (cout, 32) or w2d.dtype != torch.bfloat16 or not w2d.is_contiguous():
+        raise ValueError("conv_c1_fwd: weights must be a contiguous (Cout, 32) bf16 matrix")
+    y = torch.empty((geom.B, *geom.out, cout), dtype=torch.bfloat16, device=x.device)
+    with _Timed("conv_c1_fwd_kernel", 2.0 * geom.M * cout * 27):
+        check(_lib.load().hvc_conv_c1_fwd(x.data_ptr(), w2d.data_ptr(), _ptr(_f32c(bias, "bias")), y.data_ptr(), geom.B, *geom.src, cout,
+                                          geom.stride, _stream()), "hvc_conv_c1_fwd")
+    return y
+
+
+def conv_c1_dw(x, dy, geom):
+    """Weight and bias gradient of conv_c1_fwd: x as there, dy (B, OD, OH, OW, Cout) bf16 contiguous -> (dw (Cout, 27) fp32, db (Cout,) fp32)."""
+    _dev(x, dy)
+    cout = dy.shape[-1]
+    if not conv_c1_supported(geom, cout, x.dtype) or dy.dtype != torch.bfloat16 or not (x.is_contiguous() and dy.is_contiguous()) \
+            or dy.numel() != geom.M * cout or x.numel() != geom.B * geom.src[0] * geom.src[1] * geom.src[2]:
+        raise ValueError("conv_c1_dw: contiguous bf16 x (one channel) and dy (channels-last, 32 / 64 channels) of a k3 p1 geometry expected")
+    lib = _lib.load()
+    ws = torch.empty(lib.hvc_conv_c1_dw_workspace(geom.B, *geom.src, cout, geom.stride), dtype=torch.float32, device=x.device)
+    dw = torch.empty((cout, 32), dtype=torch.float32, device=x.device)
+    with _Timed("conv_c1_dw_kernel", 2.0 * geom.M * cout * 28):
+        check(lib.hvc_conv_c1_dw(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), geom.B, *geom.src, cout, geom.stride, _stream()),
+              "hvc_conv_c1_dw")
+    return dw[:, :27], dw[:, 27]
+
+
+def conv_o1_supported(C, dtype):
+    return dtype == torch.bfloat16 and C in (8, 16, 32, 64, 128)
+
+
+def conv_o1_fwd(x2d, w, bias):
+    """y[m] = bias + x2d[m] . w : the Conv3d(C, 1, 1) of the cascade's detail enhancer on the (M, C) view.  bf16 -> (M,) bf16."""
+    _dev(x2d, w, bias)
+    M, C = x2d.shape
+    if not conv_o1_supported(C, x2d.dtype) or not x2d.is_contiguous() or w.shape != (C,) or w.dtype != torch.bfloat16 or not w.is_contiguous():
+        raise ValueError("conv_o1_fwd: contiguous bf16 (M, C) activations and (C,) weights expected, C in {8,16,32,64,128}")
+    y = torch.empty((M,), dtype=torch.bfloat16, device=x2d.device)
+    check(_lib.load().hvc_conv_o1_fwd(x2d.data_ptr(), w.data_ptr(), _ptr(_f32c(bias, "bias")), y.data_ptr(), M, C, _stream()), "hvc_conv_o1_fwd")
+    return y
+
+
+def conv_o1_bwd(x2d, dy, w, need_dx=True):
+    """-> (dx (M, C) bf16 or None, dw (C,) fp32, db () fp32)."""
+    _dev(x2d, dy, w)
+    M, C = x2d.shape
+    if not conv_o1_supported(C, x2d.dtype) or not (x2d.is_contiguous() and dy.is_contiguous()) or dy.numel() != M or dy.dtype != torch.bfloat16 \
+            or w.shape != (C,) or w.dtype != torch.bfloat16 or not w.is_contiguous():
+        raise ValueError("conv_o1_bwd: contiguous bf16 (M, C) activations, (M,) output gradient and (C,) weights expected")
+    lib = _lib.load()
+    ws = torch.empty(lib.hvc_conv_o1_bwd_workspace(M, C), dtype=torch.float32, device=x2d.device)
+    dwb = torch.empty((C + 1,), dtype=torch.float32, device=x2d.device)
+    dx = torch.empty_like(x2d) if need_dx else None
+    check(lib.hvc_conv_o1_bwd(x2d.data_ptr(), dy.data_ptr(), w.data_ptr(), _ptr(dx), dwb.data_ptr(), ws.data_ptr(), M, C, _stream()), "hvc_conv_o1_bwd")
+    return dx, dwb[:C], dwb[C]
+
+
 def _conv_gemm_call(mode, src, other, out, geom, flip, n, bias, residual, residual_rows, ws, ws_n, flops):
     with _Timed("gemm_kernel", flops):
         check(_lib.load().hvc_conv_gemm(

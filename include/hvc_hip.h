@@ -224,6 +224,25 @@ int hvc_im2col(const void* src, void* col, int B, int C, int SD, int SH, int SW,
 int hvc_col2im(const void* dcol, void* dsrc, int B, int C, int SD, int SH, int SW, int KD, int KH, int KW,
                int stride, int PD, int PH, int PW, int OD, int64_t Kp, int dtype, void* stream);
 
+/* Single-channel convolutions as streaming kernels (bf16, channels-last; csrc/conv_direct.hip) - no patch matrix on either side:
+ *   hvc_conv_c1_*  nn.Conv3d(1, Cout, 3, stride, padding=1), Cout = 32 | 64, stride 1 | 2:
+ *                  direct_regression/progressive_cascade/model_progressive.py:171,240,260 (cascade glue, 128^3 / 256^3) and the first
+ *                  voxel-embed layer models/hybrid_vit_backbone.py:199.  x [B][SD][SH][SW], w2d [Cout][32] (tap = (kd*3 + kh)*3 + kw, columns
+ *                  27..31 ignored), y / dy [B][OD][OH][OW][Cout], O = (S - 1)/stride + 1.  hvc_conv_c1_dw returns dw [Cout][32] fp32 whose
+ *                  column 27 is the BIAS gradient (sum of dy over positions); workspace = hvc_conv_c1_dw_workspace(...) floats; partial sums
+ *                  are added in a fixed order (bitwise reproducible).  The input gradient of these layers stays on hvc_gemm + hvc_col2im.
+ *   hvc_conv_o1_*  nn.Conv3d(C, 1, 1) (model_progressive.py:266), C = 8 | 16 | 32 | 64 | 128, on the [M][C] view of the activations:
+ *                  y[m] = bias + x[m] . w;  backward: dx[m][c] = dy[m] w[c] (dx may be NULL), dwb[0..C) = sum_m dy[m] x[m][c], dwb[C] = sum_m dy[m];
+ *                  workspace = hvc_conv_o1_bwd_workspace(M, C) floats. */
+int hvc_conv_c1_fwd(const void* x, const void* w2d, const float* bias, void* y, int B, int SD, int SH, int SW, int Cout, int stride,
+                    void* stream);
+int64_t hvc_conv_c1_dw_workspace(int B, int SD, int SH, int SW, int Cout, int stride);
+int hvc_conv_c1_dw(const void* x, const void* dy, float* dw, float* workspace, int B, int SD, int SH, int SW, int Cout, int stride,
+                   void* stream);
+int hvc_conv_o1_fwd(const void* x, const void* w, const float* bias, void* y, int64_t M, int C, void* stream);
+int64_t hvc_conv_o1_bwd_workspace(int64_t M, int C);
+int hvc_conv_o1_bwd(const void* x, const void* dy, const void* w, void* dx, float* dwb, float* workspace, int64_t M, int C, void* stream);
+
 /* Convolution as an IMPLICIT GEMM (C % 8 == 0): the patch matrix above is never written; the GEMM's operand loader
  * gathers the 16-byte channel vectors of each tap straight from the channels-last activations (zero outside the volume).
  * Replaces the same nn.Conv3d / nn.Conv2d layers (models/hybrid_vit_backbone.py:195-210, models/diagnostic_losses.py:87,92,

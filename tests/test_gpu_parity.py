@@ -1514,6 +1514,66 @@ def test_conv_implicit_gemm_vs_fp64_and_im2col(cfg, dtype):
     assert torch.equal(results["implicit"][0], results["im2col"][0])
 
 
+@pytest.mark.parametrize("cfg", [
+    # B, Cin, Cout, k, stride, spatial
+    (2, 1, 32, 3, 1, (9, 10, 37)),       # cascade glue Conv3d(1, 32, 3, padding=1) (model_progressive.py:171,240): ragged blocks on every axis
+    (1, 1, 64, 3, 1, (5, 17, 33)),       # detail_enhancer[0] (model_progressive.py:260)
+    (1, 1, 32, 3, 1, (4, 8, 32)),        # exactly one output block
+    (2, 1, 64, 3, 2, (13, 9, 70)),       # first voxel-embed layer of the direct model (hybrid_vit_backbone.py:199): stride 2
+    (1, 1, 32, 3, 2, (16, 16, 64)),
+    (2, 32, 1, 1, 1, (7, 9, 11)),        # detail_enhancer[-1] Conv3d(32, 1, 1) (model_progressive.py:266): ragged row count
+    (1, 64, 1, 1, 1, (16, 16, 17)),
+    (1, 8, 1, 1, 1, (5, 5, 5)),
+    (1, 128, 1, 1, 1, (6, 10, 33)),
+])
+def test_conv_single_channel_streaming_kernels_vs_fp64_and_gemm_path(cfg):
+    """The single-channel layers of the cascade glue as streaming kernels (hvc_conv_c1_fwd / _dw, hvc_conv_o1_fwd / _bwd) against F.conv3d
+    in fp64 on the bf16-rounded operands, and against the im2col / implicit GEMM path they replace: same products, fp32 accumulation in
+    a different order, so outputs agree to a bf16 ulp and the fp32 weight / bias gradients to 1e-3."""
+    import torch.nn.functional as F
+    from hvc import functional as HF
+    from hvc import ops
+    B, Cin, Cout, k, stride, sp = cfg
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(Cin * 131 + Cout + sp[2])
+    x = torch.randn(B, Cin, *sp, generator=g)
+    w = torch.randn(Cout, Cin, k, k, k, generator=g) / (Cin * k ** 3) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    pad = k // 2
+    xr, wr, br = (t.to(dtype).double().requires_grad_(True) for t in (x, w, b))
+    y_ref = F.conv3d(xr, wr, br, stride=stride, padding=pad)
+    dy = torch.randn(y_ref.shape, generator=g)
+    y_ref.backward(dy.to(dtype).double())
+    geom = ops.ConvGeometry(B, Cin, sp, (k,) * 3, stride, (pad,) * 3)
+    results = {}
+    old = HF.CONV_DIRECT
+    try:
+        for path in ("direct", "gemm"):
+            HF.CONV_DIRECT = path == "direct"
+            xd = x.to(dev()).to(dtype).permute(0, 2, 3, 4, 1).contiguous().requires_grad_(True)
+            wd = w.to(dev()).to(dtype).float().requires_grad_(True)
+            bd = b.to(dev()).to(dtype).float().requires_grad_(True)
+            ops.PROFILE = prof = []
+            try:
+                y = HF.ConvFn.apply(xd, wd, bd, None, geom, dtype, dtype)
+            finally:
+                ops.PROFILE = None
+            (y.float() * dy.to(dev()).to(dtype).permute(0, 2, 3, 4, 1).float()).sum().backward()
+            results[path] = (y.detach().permute(0, 4, 1, 2, 3).float().cpu(), xd.grad.permute(0, 4, 1, 2, 3).float().cpu(), wd.grad.cpu(), bd.grad.cpu())
+            if Cin == 1:
+                assert (("conv_c1_fwd_kernel" in {n for n, *_ in prof}) == (path == "direct")), "the streaming kernel must be the path that ran"
+    finally:
+        HF.CONV_DIRECT = old
+    refs = (y_ref.detach(), xr.grad, wr.grad, br.grad)
+    for path, got in results.items():
+        for name, a, r, tol in zip(("y", "dx", "dw", "db"), got, refs, (8e-3, 8e-3, 1e-3 if path == "direct" else 2e-2, 1e-3 if path == "direct" else 2e-2)):
+            assert a.shape == r.shape, (path, name, a.shape, r.shape)
+            err = ((a.double() - r).abs().max() / (r.abs().max() + 1e-12)).item()
+            assert err < tol, (path, name, err)
+    for name, a, c in zip(("y", "dx"), results["direct"][:2], results["gemm"][:2]):
+        assert ((a - c).abs().max() / (c.abs().max() + 1e-12)).item() < 8e-3, name
+
+
 def test_conv_gemm_rejects_what_it_cannot_gather():
     """hvc_conv_gemm error behaviour: channel counts that are not a multiple of 8 (the gather moves 16-byte channel vectors; such
     layers stay on im2col), a wrong weight shape, a wrong activation shape and depth-slab geometries raise instead of computing."""
