@@ -12,7 +12,7 @@
 //                   wavefront-private LDS stage so that the channels-last stores are 16 bytes per lane, 1 - 2 KiB contiguous per row.
 //   * conv_c1_dw  : the same halo and tap gather, now as the B operand of dW[co][tap] = sum_voxels dy[voxel][co] patch[voxel][tap]; dy rows
 //                   are streamed once (the only HBM traffic that matters), transposed through LDS (ds_read_b64_tr_b16).  Tap 27 of the
-//                   padded patch is the constant 1, so column 27 of the result is the bias gradient.  Per-wavefront fp32 partials, summed
+//                   padded patch is the constant 1, so column 27 of the result is the bias gradient.  Per-workgroup fp32 partials, summed
 //                   in a fixed order by a second kernel (deterministic, as the split-K weight gradients of gemm.hip).
 //   * conv_1x1_o1_fwd / _bwd : row dot products / outer products, 16 bytes per lane.
 #include "hvc_common.hip.h"
@@ -212,23 +212,35 @@ __global__ __launch_bounds__(256) void conv_c1_dw_kernel(const ConvC1Args a) {
             for (int k = 0; k < 2 * NT; ++k) cur[k] = nxt[k];
         }
     }
-    // rows = co (registers), column = tap (lane)
-    float* ws = a.workspace + ((size_t)blockIdx.x * 4 + wave) * (a.Cout * kTapPad);
+    // rows = co (registers), column = tap (lane).  The four wavefronts' tiles are added in wavefront order through LDS (the dy tiles
+    // are free now), so the second pass sums one partial per workgroup.
+    float* red = reinterpret_cast<float*>(dyt_all);
+    static_assert(sizeof(float) * 32 * NT * kTapPad <= sizeof(bf16) * 4 * kTX * CW, "the partial tile fits the dy tiles");
+    for (int w = 0; w < 4; ++w) {
+        __syncthreads();
+        if (wave == w) {
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
+            for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) ws[(32 * nt + acc_row(e, h)) * kTapPad + r] = acc[nt][e];
+                for (int e = 0; e < 16; ++e) {
+                    float* p = red + (32 * nt + acc_row(e, h)) * kTapPad + r;
+                    const float v = w == 0 ? acc[nt][e] : *p + acc[nt][e];
+                    if (w == 3) a.workspace[(size_t)blockIdx.x * (a.Cout * kTapPad) + (32 * nt + acc_row(e, h)) * kTapPad + r] = v;
+                    else *p = v;
+                }
+        }
+    }
 }
 
-// dw[e] = sum over the partials, fixed order: a block takes 32 consecutive outputs, its 256 threads = 32 outputs x 8 row groups
+// dw[e] = sum over the partials, fixed order: a block takes 16 consecutive outputs, its 256 threads = 16 outputs x 16 row groups
 __global__ __launch_bounds__(256) void conv_c1_dw_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int n, int parts) {
-    __shared__ float red[8][32];
-    const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
-    const int e = blockIdx.x * 32 + cl;
+    __shared__ float red[16][16];
+    const int cl = threadIdx.x & 15, rg = threadIdx.x >> 4;
+    const int e = blockIdx.x * 16 + cl;
     float s0 = 0.f, s1 = 0.f;
     if (e < n) {
         int p = rg;
-        for (; p + 8 < parts; p += 16) { s0 += ws[(size_t)p * n + e]; s1 += ws[(size_t)(p + 8) * n + e]; }
+        for (; p + 16 < parts; p += 32) { s0 += ws[(size_t)p * n + e]; s1 += ws[(size_t)(p + 16) * n + e]; }
         if (p < parts) s0 += ws[(size_t)p * n + e];
     }
     red[rg][cl] = s0 + s1;
@@ -236,7 +248,7 @@ __global__ __launch_bounds__(256) void conv_c1_dw_reduce_kernel(const float* __r
     if (rg == 0 && e < n) {
         float s = 0.f;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) s += red[k][cl];
+        for (int k = 0; k < 16; ++k) s += red[k][cl];
         dw[e] = s;
     }
 }
@@ -344,8 +356,7 @@ int conv_c1_dw_parts(int B, int SD, int SH, int SW, int stride) {
     ConvC1Args a{};
     a.B = B; a.SD = SD; a.SH = SH; a.SW = SW; a.stride = stride;
     fill_tiles(a);
-    const int grid = a.ntiles < 4 * cu_count() ? a.ntiles : 4 * cu_count();
-    return grid * 4;
+    return a.ntiles < 4 * cu_count() ? a.ntiles : 4 * cu_count();       // one partial per workgroup
 }
 
 hipError_t conv_c1_fwd_launch(ConvC1Args a, hipStream_t st) {
@@ -359,13 +370,13 @@ hipError_t conv_c1_fwd_launch(ConvC1Args a, hipStream_t st) {
 hipError_t conv_c1_dw_launch(ConvC1Args a, float* dw, hipStream_t st) {
     fill_tiles(a);
     if (!conv_c1_supported(a.Cout, a.stride)) return hipErrorInvalidValue;
-    const int parts = conv_c1_dw_parts(a.B, a.SD, a.SH, a.SW, a.stride), grid = parts / 4;
+    const int parts = conv_c1_dw_parts(a.B, a.SD, a.SH, a.SW, a.stride), grid = parts;
     if (a.stride == 1) { if (a.Cout == 32) launch_c1(conv_c1_dw_kernel<1, 1>, grid, a, st); else launch_c1(conv_c1_dw_kernel<1, 2>, grid, a, st); }
     else { if (a.Cout == 32) launch_c1(conv_c1_dw_kernel<2, 1>, grid, a, st); else launch_c1(conv_c1_dw_kernel<2, 2>, grid, a, st); }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const int n = a.Cout * kTapPad;
-    hipLaunchKernelGGL(conv_c1_dw_reduce_kernel, dim3((n + 31) / 32), dim3(256), 0, st, a.workspace, dw, n, parts);
+    hipLaunchKernelGGL(conv_c1_dw_reduce_kernel, dim3((n + 15) / 16), dim3(256), 0, st, a.workspace, dw, n, parts);
     return hipGetLastError();
 }
 
@@ -408,7 +419,7 @@ hipError_t conv_o1_bwd_launch(const void* x, const void* dy, const void* w, void
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const int n = C + 1;
-    hipLaunchKernelGGL(conv_c1_dw_reduce_kernel, dim3((n + 31) / 32), dim3(256), 0, st, workspace, dwb, n, grid);
+    hipLaunchKernelGGL(conv_c1_dw_reduce_kernel, dim3((n + 15) / 16), dim3(256), 0, st, workspace, dwb, n, grid);
     return hipGetLastError();
 }
 

@@ -215,7 +215,7 @@ struct ConvC1Args {
     const float* bias;       // [Cout] or null
     void* y;                 // [B][OD][OH][OW][Cout] bf16
     const void* dy;          // the same shape (weight gradient)
-    float* workspace;        // weight gradient: conv_c1_dw_parts() x Cout x 32 floats
+    float* workspace;        // weight gradient: conv_c1_dw_parts() x Cout x 32 floats (one partial per workgroup)
     int B, SD, SH, SW, Cout, stride;
     int OD, OH, OW, tiles_x, tiles_y, tiles_z, ntiles;      // filled by the launchers
 };
