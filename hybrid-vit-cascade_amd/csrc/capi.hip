@@ -426,6 +426,16 @@ int hvc_conv_c1_dw(const void* x, const void* dy, float* dw, float* workspace, i
     return hip_result(hvc::conv_c1_dw_launch(a, dw, (hipStream_t)stream), "conv_c1_dw");
 }
 
+int hvc_conv3_halo(const void* x, const void* wfrag, const float* bias, void* y, int B, int D, int H, int W, int CI, int CO, void* stream) {
+    if (!x || !wfrag || !y) return fail(HVC_E_BADARG, "conv3_halo: null operand");
+    if (B < 1 || D < 1 || H < 1 || W < 1) return fail(HVC_E_BADARG, "conv3_halo: empty volume");
+    if (!hvc::conv3_halo_supported(CI, CO)) return fail(HVC_E_UNSUPPORTED, "conv3_halo: channel counts must be 32 or 64 (use conv_gemm)");
+    if (!aligned16(x) || !aligned16(wfrag) || !aligned16(y)) return fail(HVC_E_BADARG, "conv3_halo: operands must be 16-byte aligned");
+    hvc::Conv3Args a{};
+    a.x = x; a.wfrag = wfrag; a.bias = bias; a.y = y; a.B = B; a.D = D; a.H = H; a.W = W; a.CI = CI; a.CO = CO;
+    return hip_result(hvc::conv3_halo_launch(a, (hipStream_t)stream), "conv3_halo");
+}
+
 int hvc_conv_o1_fwd(const void* x, const void* w, const float* bias, void* y, int64_t M, int C, void* stream) {
     if (!x || !w || !y || M < 1) return fail(HVC_E_BADARG, "conv_o1_fwd: bad operand");
     if (!hvc::conv_o1_supported(C)) return fail(HVC_E_UNSUPPORTED, "conv_o1_fwd: C must be 8, 16, 32, 64 or 128 (use conv_gemm)");

@@ -339,6 +339,165 @@ __global__ __launch_bounds__(256) void conv_o1_bwd_kernel(const bf16* __restrict
     }
 }
 
+// ---- 3 x 3 x 3, stride 1, 32 | 64 -> 32 | 64 channels: LDS halo tile ------------------------------------------------------------------
+// (model_progressive.py:263 Conv3d(64, 32, 3, padding=1) at 256^3 and its input gradient.)  As an implicit GEMM every tap re-fetches its
+// 128-byte channel vectors from L2: 27 x the input, 56 GB per pass at 256^3, and the pass runs at L2 speed (3.8 ms).  Here a workgroup
+// stages the halo of a 2 x 8 x 32 output block once per 16-channel slice (4 x 10 x 34 voxels x 32 B, slots 48 B apart: the 16 slots a
+// ds_read_b128 group touches land on distinct banks) and every tap reads its patch fragment from LDS at a constant offset.
+// With 32 output channels a patch fragment feeds ONE MFMA per tap - 1 KiB of LDS per 32-cycle MFMA is all the LDS delivers - so the
+// fragment is reused across the kh taps instead: a wavefront owns four consecutive output rows (same z) and a halo row read once for
+// (kd, kw) goes into up to three of them (kh = 0, 1, 2) against three register-resident weight fragments: 6 reads per 12 MFMAs.
+// Weight fragments come from global memory pre-arranged lane-linear by the host (1 KiB per load).  Accumulator rows = output channel,
+// column = voxel; stores go through LDS as in conv_c1_fwd.
+constexpr int kBZ = 2, kBY = 8, kBX = 32;                     // output block
+constexpr int kHZ = kBZ + 2, kHY = kBY + 2, kHX = kBX + 2;    // its halo: 4 x 10 x 34 = 1360 voxels
+constexpr int kHSlot = 24;                                    // bf16 per halo voxel slot: 16 channels + 8 (48-byte stride)
+
+template <int CI, int CO>
+__global__ __launch_bounds__(256, 2) void conv3_halo_kernel(const Conv3Args a) {
+    constexpr int NCK = CI / 16, NT = CO / 32;
+    constexpr int ROWB = 64 * NT + 16;                        // store stage: bytes per voxel
+    static_assert(4 * kBX * ROWB <= kHZ * kHY * kHX * kHSlot * 2, "the store stage fits the halo");
+    __shared__ __attribute__((aligned(16))) bf16 halo[kHZ * kHY * kHX * kHSlot];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+    int t = blockIdx.x;
+    const int x0 = (t % a.tiles_x) * kBX; t /= a.tiles_x;
+    const int y0 = (t % a.tiles_y) * kBY; t /= a.tiles_y;
+    const int z0 = (t % a.tiles_z) * kBZ;
+    const int b = t / a.tiles_z;
+    const bf16* xb = reinterpret_cast<const bf16*>(a.x) + (int64_t)b * a.D * a.H * a.W * CI;
+    const bf16x8* wf = reinterpret_cast<const bf16x8*>(a.wfrag) + lane;
+    const int zw = wave >> 1, yw = 4 * (wave & 1);            // this wavefront's rows: (zw, yw + j), j = 0..3
+
+    f32x16 acc[4][NT];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[j][nt][e] = a.bias ? a.bias[32 * nt + acc_row(e, h)] : 0.f;
+    // this lane's patch origin: halo voxel (zw, yw, r) + its 8-channel half
+    const bf16* pbase = halo + ((zw * kHY + yw) * kHX + r) * kHSlot + 8 * h;
+
+    // weight fragments [tap][ck][nt][lane]: the three kh taps of one (kd, kw), one group ahead in registers
+    auto load_w = [&](int ck, int g, bf16x8 (&w)[3][NT]) {      // g = kd * 3 + kw
+        const int kd = g / 3, kw = g % 3;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) w[kh][nt] = wf[(size_t)((((kd * 3 + kh) * 3 + kw) * NCK + ck) * NT + nt) * 64];
+    };
+
+    // The slice's weight fragments sit PD groups ahead in registers (all nine at 32 output channels): a group's loads have PD x 12
+    // MFMAs - or, for the first ones, the halo staging and its barrier - to arrive; one group ahead they did not (L2 latency > 12 MFMAs).
+    // At 32 output channels the registers also hold the NEXT slice's halo pieces, requested right after the barrier that publishes the
+    // current slice, so that their latency runs under the slice's 108 MFMAs (AHEAD); at 64 the accumulators leave no room and a slice's
+    // pieces are fetched in two batches between the barriers.
+    constexpr bool AHEAD = NT == 1;
+    constexpr int PD = NT == 1 ? 3 : 2;
+    constexpr int HN = kHZ * kHY * kHX * 2;                     // 16-byte halo pieces per slice
+    constexpr int HITER = (HN + 255) / 256, HB = AHEAD ? HITER : (HITER + 1) / 2;
+    bf16x8 hreg[HB];
+    auto halo_fetch = [&](int ck, int first) {                  // pieces first .. first + HB - 1 of this thread -> registers
+#pragma unroll
+        for (int it = 0; it < HB; ++it) {
+            const int e = tid + 256 * (first + it);
+            const int piece = e & 1, hv = e >> 1;
+            const int hx = hv % kHX, q = hv / kHX, hy = q % kHY, hz = q / kHY;
+            const int sz = z0 - 1 + hz, sy = y0 - 1 + hy, sx = x0 - 1 + hx;
+            hreg[it] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            if (e < HN && sz >= 0 && sz < a.D && sy >= 0 && sy < a.H && sx >= 0 && sx < a.W)
+                hreg[it] = *reinterpret_cast<const bf16x8*>(xb + (((int64_t)sz * a.H + sy) * a.W + sx) * CI + 16 * ck + 8 * piece);
+        }
+    };
+    auto halo_commit = [&](int first) {
+#pragma unroll
+        for (int it = 0; it < HB; ++it) {
+            const int e = tid + 256 * (first + it);
+            if (e < HN) *reinterpret_cast<bf16x8*>(halo + (e >> 1) * kHSlot + 8 * (e & 1)) = hreg[it];
+        }
+    };
+    if constexpr (AHEAD) halo_fetch(0, 0);
+#pragma unroll 1
+    for (int ck = 0; ck < NCK; ++ck) {
+        bf16x8 wbuf[PD][3][NT];
+#pragma unroll
+        for (int g = 0; g < PD; ++g) load_w(ck, g, wbuf[g]);
+        if constexpr (AHEAD) {
+            if (ck) __syncthreads();                           // the previous slice has been read
+            halo_commit(0);
+        } else {
+            halo_fetch(ck, 0);
+            if (ck) __syncthreads();
+            halo_commit(0);
+            halo_fetch(ck, HB);
+            halo_commit(HB);
+        }
+        __syncthreads();
+        if constexpr (AHEAD) {
+            if (ck + 1 < NCK) halo_fetch(ck + 1, 0);
+        }
+        // patch fragments of group g + 1 are requested ahead of group g's MFMAs (AHEAD; hipcc otherwise issues each read directly in
+        // front of its first MFMA and the wavefront sits through the LDS latency six times per group)
+        auto read_patches = [&](int g, bf16x8 (&pf)[6]) {
+            const bf16* pg = pbase + ((g / 3) * kHY * kHX + g % 3) * kHSlot;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) pf[i] = *reinterpret_cast<const bf16x8*>(pg + i * (kHX * kHSlot));
+        };
+        bf16x8 pfc[6], pfn[6];
+        read_patches(0, pfc);
+#pragma unroll
+        for (int g = 0; g < 9; ++g) {
+            if constexpr (AHEAD) {
+                if (g + 1 < 9) read_patches(g + 1, pfn);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh) {
+                    const int j = i - kh;
+                    if (j >= 0 && j < 4) {
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) acc[j][nt] = mfma32(wbuf[g % PD][kh][nt], pfc[i], acc[j][nt]);
+                    }
+                }
+            if (g + PD < 9) load_w(ck, g + PD, wbuf[g % PD]);
+            if (g + 1 < 9) {
+                if constexpr (AHEAD) {
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) pfc[i] = pfn[i];
+                } else {
+                    read_patches(g + 1, pfc);
+                }
+            }
+        }
+    }
+    __syncthreads();                                            // the halo is free: it becomes the store stage
+    char* st = reinterpret_cast<char*>(halo) + wave * (kBX * ROWB);
+    bf16* yb = reinterpret_cast<bf16*>(a.y);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int oz = z0 + zw, oy = y0 + yw + j;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const uint32_t lo = pack2(f2bf(acc[j][nt][4 * g]), f2bf(acc[j][nt][4 * g + 1])), hi = pack2(f2bf(acc[j][nt][4 * g + 2]), f2bf(acc[j][nt][4 * g + 3]));
+                typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+                *reinterpret_cast<u32x2*>(st + r * ROWB + (32 * nt + 8 * g + 4 * h) * 2) = (u32x2){lo, hi};
+            }
+        if (oz >= a.D || oy >= a.H) continue;                   // wave-uniform
+        bf16* yrow = yb + ((((int64_t)b * a.D + oz) * a.H + oy) * a.W + x0) * CO;
+#pragma unroll
+        for (int k = 0; k < 2 * NT; ++k) {
+            const int cc = lane + 64 * k, vox = cc / (4 * NT), part = cc % (4 * NT);
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(st + vox * ROWB + part * 16);
+            if (x0 + vox < a.W) *reinterpret_cast<bf16x8*>(yrow + vox * CO + part * 8) = v;
+        }
+    }
+}
+
 template <typename K>
 void launch_c1(K kernel, int grid, const ConvC1Args& a, hipStream_t st) { hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), 0, st, a); }
 
@@ -377,6 +536,21 @@ hipError_t conv_c1_dw_launch(ConvC1Args a, float* dw, hipStream_t st) {
     if (e != hipSuccess) return e;
     const int n = a.Cout * kTapPad;
     hipLaunchKernelGGL(conv_c1_dw_reduce_kernel, dim3((n + 15) / 16), dim3(256), 0, st, a.workspace, dw, n, parts);
+    return hipGetLastError();
+}
+
+bool conv3_halo_supported(int CI, int CO) { return (CI == 32 || CI == 64) && (CO == 32 || CO == 64); }
+
+hipError_t conv3_halo_launch(Conv3Args a, hipStream_t st) {
+    if (!conv3_halo_supported(a.CI, a.CO)) return hipErrorInvalidValue;
+    a.tiles_x = (a.W + kBX - 1) / kBX; a.tiles_y = (a.H + kBY - 1) / kBY; a.tiles_z = (a.D + kBZ - 1) / kBZ;
+    const int64_t n = (int64_t)a.B * a.tiles_z * a.tiles_y * a.tiles_x;
+    if (n > 0x7fffffff) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)n), blk(256);
+    if (a.CI == 64 && a.CO == 32) hipLaunchKernelGGL((conv3_halo_kernel<64, 32>), grid, blk, 0, st, a);
+    else if (a.CI == 32 && a.CO == 64) hipLaunchKernelGGL((conv3_halo_kernel<32, 64>), grid, blk, 0, st, a);
+    else if (a.CI == 32 && a.CO == 32) hipLaunchKernelGGL((conv3_halo_kernel<32, 32>), grid, blk, 0, st, a);
+    else hipLaunchKernelGGL((conv3_halo_kernel<64, 64>), grid, blk, 0, st, a);
     return hipGetLastError();
 }
 

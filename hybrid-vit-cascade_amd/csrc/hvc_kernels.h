@@ -223,6 +223,17 @@ bool conv_c1_supported(int Cout, int stride);
 int conv_c1_dw_parts(int B, int SD, int SH, int SW, int stride);
 hipError_t conv_c1_fwd_launch(ConvC1Args a, hipStream_t st);
 hipError_t conv_c1_dw_launch(ConvC1Args a, float* dw, hipStream_t st);      // dw: [Cout][32] fp32, column 27 = bias gradient
+// Conv3d(CI -> CO, k3, s1, p1), CI, CO in {32, 64}, bf16 channels-last, through an LDS halo tile (conv_direct.hip).
+struct Conv3Args {
+    const void* x;           // [B][D][H][W][CI]
+    const void* wfrag;       // weight fragments [27 taps][CI/16][CO/32][64 lanes][8]: element j of lane l = W[32 nt + (l & 31)][tap][16 ck + 8 (l >> 5) + j]
+    const float* bias;       // [CO] or null
+    void* y;                 // [B][D][H][W][CO]
+    int B, D, H, W, CI, CO;
+    int tiles_x, tiles_y, tiles_z;      // filled by the launcher
+};
+bool conv3_halo_supported(int CI, int CO);
+hipError_t conv3_halo_launch(Conv3Args a, hipStream_t st);
 bool conv_o1_supported(int C);
 int conv_o1_bwd_blocks(int64_t M, int C);
 hipError_t conv_o1_fwd_launch(const void* x, const void* w, const float* bias, void* y, int64_t M, int C, hipStream_t st);

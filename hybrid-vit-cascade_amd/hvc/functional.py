@@ -161,7 +161,26 @@ def _conv_w2dC_fill(dst, w):
     dst.view(cin, taps, cout).copy_(w.detach().reshape(cout, cin, taps).permute(1, 2, 0).index_select(1, w._hvc_w2dC_perm))
 
 
-_CONV_FILL = {"_hvc_w2d": _conv_w2d_fill, "_hvc_w2dT": _conv_w2dT_fill, "_hvc_w2dC": _conv_w2dC_fill}
+def _frag_order(w3):
+    """(CO, 27, CI) -> MFMA fragment order [tap][ck][nt][h][r][8] of hvc_conv3_halo (lane = 32 h + r, 16-channel slices ck)."""
+    co, taps, ci = w3.shape
+    return w3.reshape(co // 32, 32, taps, ci // 16, 2, 8).permute(2, 3, 0, 4, 1, 5)
+
+
+def _conv_wfrag_fill(dst, w):
+    """forward operand: W[co][tap][ci]"""
+    co, ci = w.shape[0], w.shape[1]
+    dst.view(27, ci // 16, co // 32, 2, 32, 8).copy_(_frag_order(w.detach().reshape(co, ci, 27).permute(0, 2, 1)))
+
+
+def _conv_wfragT_fill(dst, w):
+    """input-gradient operand: the convolution of dy with the mirrored kernel, W'[ci][tap'][co] = W[co][ci][26 - tap']"""
+    co, ci = w.shape[0], w.shape[1]
+    dst.view(27, co // 16, ci // 32, 2, 32, 8).copy_(_frag_order(w.detach().reshape(co, ci, 27).flip(2).permute(1, 2, 0)))
+
+
+_CONV_FILL = {"_hvc_w2d": _conv_w2d_fill, "_hvc_w2dT": _conv_w2dT_fill, "_hvc_w2dC": _conv_w2dC_fill,
+              "_hvc_wfrag": _conv_wfrag_fill, "_hvc_wfragT": _conv_wfragT_fill}
 
 
 def _after_optimizer_step(optimizer, args, kwargs):
@@ -534,6 +553,25 @@ def conv_weight_2d(weight: torch.Tensor, dtype: torch.dtype, Kp: int) -> torch.T
     return w2
 
 
+def conv_weight_frags(weight: torch.Tensor, dtype: torch.dtype, transposed: bool = False) -> torch.Tensor:
+    """(Cout, Cin, 3, 3, 3) parameter -> the fragment-ordered operand of ops.conv3_halo (forward, or with transposed=True the input
+    gradient: mirrored taps, channels swapped); cached like conv_weight_2d."""
+    attr = "_hvc_wfragT" if transposed else "_hvc_wfrag"
+    key = _cache_key(weight, dtype)
+    hit = getattr(weight, attr, None)
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    wf = torch.empty((weight.numel(),), dtype=dtype, device=weight.device)
+    with torch.no_grad():
+        _CONV_FILL[attr](wf, weight)
+    try:
+        setattr(weight, attr, (key, wf))
+        _register(weight, attr)
+    except AttributeError:
+        pass
+    return wf
+
+
 def conv_weight_2d_t(weight: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     """(Cout, Cin, *k) parameter -> (Cin, taps*Cout) operand of the implicit-GEMM input gradient; cached like conv_weight_2d."""
     key = _cache_key(weight, dtype)
@@ -661,7 +699,12 @@ class ConvFn(torch.autograd.Function):
             if slabbed:
                 raise RuntimeError("ConvFn: the fused pos_embed add is only supported for un-slabbed (token-sized) outputs")
             add = _f32(addvec).reshape(-1, cout)
-        if implicit:
+        halo = implicit and CONV_DIRECT and add is None and out_dtype == cdt and ops.conv3_halo_supported(geom, cout, cdt)
+        if halo:
+            xc = xc.contiguous()
+            y = ops.conv3_halo(xc, conv_weight_frags(weight, cdt), _f32(bias), cout)
+            ctx.save_for_backward(xc, weight)
+        elif implicit:
             xc = xc.contiguous()
             y = ops.conv_gemm(xc, w2d, geom, bias=_f32(bias), residual=add, residual_rows=add.shape[0] if add is not None else 0,
                               out_dtype=out_dtype)
@@ -723,7 +766,10 @@ class ConvFn(torch.autograd.Function):
             if ctx.needs_input_grad[1]:
                 dw2d = ops.conv_gemm_dw(xc, dyc, geom)                                                   # (Cout, taps*C)
             if ctx.needs_input_grad[0]:
-                if geom.stride == 1 and cout % 8 == 0:
+                if CONV_DIRECT and ops.conv3_halo_supported(geom, cout, cdt):
+                    # the mirrored-kernel convolution of dy through the LDS halo tile
+                    dx = ops.conv3_halo(dyc.view(geom.B, *geom.out, cout), conv_weight_frags(weight, cdt, transposed=True), None, geom.C)
+                elif geom.stride == 1 and cout % 8 == 0:
                     # dx as an implicit GEMM over dy with the mirrored kernel: no dcol matrix, no col2im
                     gd = ops.ConvGeometry(geom.B, cout, geom.out, geom.kernel, 1, tuple(k - 1 - p for k, p in zip(geom.kernel, geom.pad)))
                     assert gd.out == geom.src

@@ -461,6 +461,27 @@ def conv_c1_dw(x, dy, geom):
     return dw[:, :27], dw[:, 27]
 
 
+def conv3_halo_supported(geom, cout, dtype):
+    """Conv3d(32 | 64 -> 32 | 64, k3, s1, p1) on bf16 activations: the layers hvc_conv3_halo covers."""
+    return (dtype == torch.bfloat16 and geom.C in (32, 64) and cout in (32, 64) and geom.kernel == (3, 3, 3) and geom.pad == (1, 1, 1)
+            and geom.stride == 1 and not geom.out_depth)
+
+
+def conv3_halo(x, wfrag, bias, cout):
+    """x: (B, D, H, W, CI) bf16 contiguous; wfrag: weight fragments (functional.conv_weight_frags) -> (B, D, H, W, cout) bf16."""
+    _dev(x, wfrag, bias)
+    B, D, H, W, CI = x.shape
+    if x.dtype != torch.bfloat16 or not x.is_contiguous() or CI not in (32, 64) or cout not in (32, 64):
+        raise ValueError("conv3_halo: contiguous bf16 channels-last activations with 32 / 64 channels expected")
+    if wfrag.dtype != torch.bfloat16 or not wfrag.is_contiguous() or wfrag.numel() != 27 * CI * cout:
+        raise ValueError("conv3_halo: wfrag must hold 27 * CI * CO bf16 weights in fragment order")
+    y = torch.empty((B, D, H, W, cout), dtype=torch.bfloat16, device=x.device)
+    with _Timed("conv3_halo_kernel", 2.0 * B * D * H * W * cout * 27 * CI):
+        check(_lib.load().hvc_conv3_halo(x.data_ptr(), wfrag.data_ptr(), _ptr(_f32c(bias, "bias")), y.data_ptr(), B, D, H, W, CI, cout, _stream()),
+              "hvc_conv3_halo")
+    return y
+
+
 def conv_o1_supported(C, dtype):
     return dtype == torch.bfloat16 and C in (8, 16, 32, 64, 128)
 

@@ -239,6 +239,11 @@ int hvc_conv_c1_fwd(const void* x, const void* w2d, const float* bias, void* y, 
 int64_t hvc_conv_c1_dw_workspace(int B, int SD, int SH, int SW, int Cout, int stride);
 int hvc_conv_c1_dw(const void* x, const void* dy, float* dw, float* workspace, int B, int SD, int SH, int SW, int Cout, int stride,
                    void* stream);
+/* nn.Conv3d(CI, CO, 3, padding=1), CI, CO in {32, 64}, bf16 channels-last, through an LDS halo tile instead of a 27-fold gather from L2:
+ * direct_regression/progressive_cascade/model_progressive.py:263 (detail_enhancer 64 -> 32 at 256^3) and, with mirrored taps and transposed
+ * weights, its input gradient.  wfrag: the weights pre-arranged in MFMA fragment order, [27 taps][CI/16][CO/32][64 lanes][8] bf16 with
+ * element j of lane l = W[32 nt + (l & 31)][tap][16 ck + 8 (l >> 5) + j], W = (CO, tap = (kd*3 + kh)*3 + kw, CI). */
+int hvc_conv3_halo(const void* x, const void* wfrag, const float* bias, void* y, int B, int D, int H, int W, int CI, int CO, void* stream);
 int hvc_conv_o1_fwd(const void* x, const void* w, const float* bias, void* y, int64_t M, int C, void* stream);
 int64_t hvc_conv_o1_bwd_workspace(int64_t M, int C);
 int hvc_conv_o1_bwd(const void* x, const void* dy, const void* w, void* dx, float* dwb, float* workspace, int64_t M, int C, void* stream);

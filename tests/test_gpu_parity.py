@@ -1493,7 +1493,8 @@ def test_conv_implicit_gemm_vs_fp64_and_im2col(cfg, dtype):
     to_cl = lambda t: (t if is3d else t.unsqueeze(2)).permute(0, 2, 3, 4, 1).contiguous()
     from_cl = lambda t: (lambda u: u if is3d else u.squeeze(2))(t.permute(0, 4, 1, 2, 3))
     results = {}
-    old = HF.CONV_IMPLICIT
+    old, old_direct = HF.CONV_IMPLICIT, HF.CONV_DIRECT
+    HF.CONV_DIRECT = False           # this test is about the GEMM paths (the streaming / halo-tile kernels have their own below)
     try:
         for path in ("implicit", "im2col"):
             HF.CONV_IMPLICIT = path == "implicit"
@@ -1504,7 +1505,7 @@ def test_conv_implicit_gemm_vs_fp64_and_im2col(cfg, dtype):
             (y.float() * to_cl(dy.to(dev()).to(dtype)).float()).sum().backward()
             results[path] = (from_cl(y.detach()).float().cpu(), from_cl(xd.grad).float().cpu(), wd.grad.cpu(), bd.grad.cpu())
     finally:
-        HF.CONV_IMPLICIT = old
+        HF.CONV_IMPLICIT, HF.CONV_DIRECT = old, old_direct
     tol = 1e-4 if dtype == torch.float32 else 2e-2
     refs = (y_ref.detach(), xr.grad, wr.grad, br.grad)
     for path, got in results.items():
@@ -1525,6 +1526,10 @@ def test_conv_implicit_gemm_vs_fp64_and_im2col(cfg, dtype):
     (1, 64, 1, 1, 1, (16, 16, 17)),
     (1, 8, 1, 1, 1, (5, 5, 5)),
     (1, 128, 1, 1, 1, (6, 10, 33)),
+    (2, 64, 32, 3, 1, (5, 9, 37)),       # detail_enhancer[3] Conv3d(64, 32, 3, padding=1) (model_progressive.py:263) through the LDS halo tile
+    (1, 32, 64, 3, 1, (4, 6, 33)),       # (hvc_conv3_halo), forward and - mirrored taps, swapped channels - input gradient; ragged blocks
+    (1, 32, 32, 3, 1, (2, 8, 32)),       # exactly one block
+    (1, 64, 64, 3, 1, (3, 5, 70)),
 ])
 def test_conv_single_channel_streaming_kernels_vs_fp64_and_gemm_path(cfg):
     """The single-channel layers of the cascade glue as streaming kernels (hvc_conv_c1_fwd / _dw, hvc_conv_o1_fwd / _bwd) against F.conv3d
@@ -1560,13 +1565,17 @@ def test_conv_single_channel_streaming_kernels_vs_fp64_and_gemm_path(cfg):
                 ops.PROFILE = None
             (y.float() * dy.to(dev()).to(dtype).permute(0, 2, 3, 4, 1).float()).sum().backward()
             results[path] = (y.detach().permute(0, 4, 1, 2, 3).float().cpu(), xd.grad.permute(0, 4, 1, 2, 3).float().cpu(), wd.grad.cpu(), bd.grad.cpu())
+            ran = {n for n, *_ in prof}
             if Cin == 1:
-                assert (("conv_c1_fwd_kernel" in {n for n, *_ in prof}) == (path == "direct")), "the streaming kernel must be the path that ran"
+                assert ("conv_c1_fwd_kernel" in ran) == (path == "direct"), "the streaming kernel must be the path that ran"
+            elif k == 3:
+                assert ("conv3_halo_kernel" in ran) == (path == "direct"), "the halo-tile kernel must be the path that ran"
     finally:
         HF.CONV_DIRECT = old
     refs = (y_ref.detach(), xr.grad, wr.grad, br.grad)
     for path, got in results.items():
-        for name, a, r, tol in zip(("y", "dx", "dw", "db"), got, refs, (8e-3, 8e-3, 1e-3 if path == "direct" else 2e-2, 1e-3 if path == "direct" else 2e-2)):
+        wtol = 1e-3 if path == "direct" and 1 in (Cin, Cout) else 2e-2
+        for name, a, r, tol in zip(("y", "dx", "dw", "db"), got, refs, (8e-3, 8e-3, wtol, wtol)):
             assert a.shape == r.shape, (path, name, a.shape, r.shape)
             err = ((a.double() - r).abs().max() / (r.abs().max() + 1e-12)).item()
             assert err < tol, (path, name, err)
