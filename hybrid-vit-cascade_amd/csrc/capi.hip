@@ -426,6 +426,16 @@ int hvc_conv_c1_dw(const void* x, const void* dy, float* dw, float* workspace, i
     return hip_result(hvc::conv_c1_dw_launch(a, dw, (hipStream_t)stream), "conv_c1_dw");
 }
 
+int hvc_conv_c1_dx(const void* dy, const void* wt, void* dx, int B, int D, int H, int W, int Cout, void* stream) {
+    if (!dy || !wt || !dx) return fail(HVC_E_BADARG, "conv_c1_dx: null operand");
+    if (B < 1 || D < 1 || H < 1 || W < 1) return fail(HVC_E_BADARG, "conv_c1_dx: empty volume");
+    if (!hvc::conv_c1_supported(Cout, 1)) return fail(HVC_E_UNSUPPORTED, "conv_c1_dx: Cout must be 32 or 64 (use gemm + col2im)");
+    if (!aligned16(dy) || !aligned16(wt)) return fail(HVC_E_BADARG, "conv_c1_dx: dy and wt must be 16-byte aligned");
+    hvc::ConvC1Args a{};
+    a.dy = dy; a.w2d = wt; a.y = dx; a.B = B; a.SD = D; a.SH = H; a.SW = W; a.Cout = Cout; a.stride = 1;
+    return hip_result(hvc::conv_c1_dx_launch(a, (hipStream_t)stream), "conv_c1_dx");
+}
+
 int hvc_conv3_halo(const void* x, const void* wfrag, const float* bias, void* y, int B, int D, int H, int W, int CI, int CO, void* stream) {
     if (!x || !wfrag || !y) return fail(HVC_E_BADARG, "conv3_halo: null operand");
     if (B < 1 || D < 1 || H < 1 || W < 1) return fail(HVC_E_BADARG, "conv3_halo: empty volume");

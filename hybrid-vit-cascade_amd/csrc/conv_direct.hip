@@ -14,6 +14,7 @@
 //                   are streamed once (the only HBM traffic that matters), transposed through LDS (ds_read_b64_tr_b16).  Tap 27 of the
 //                   padded patch is the constant 1, so column 27 of the result is the bias gradient.  Per-workgroup fp32 partials, summed
 //                   in a fixed order by a second kernel (deterministic, as the split-K weight gradients of gemm.hip).
+//   * conv_c1_dx  : the dcol tile of the input gradient stays in LDS (MFMA per halo voxel, then a 27-entry gather per output voxel).
 //   * conv_1x1_o1_fwd / _bwd : row dot products / outer products, 16 bytes per lane.
 #include "hvc_common.hip.h"
 #include "hvc_kernels.h"
@@ -230,6 +231,78 @@ __global__ __launch_bounds__(256) void conv_c1_dw_kernel(const ConvC1Args a) {
                 }
         }
     }
+}
+
+// ---- input gradient of the Cin = 1 layers (stride 1):  dx[p] = sum_tap sum_co dy[p - (tap - 1)][co] w[co][tap] ---------------------------
+// Through hvc_gemm + hvc_col2im this was a [voxels][32] dcol matrix written and gathered again (0.67 + 2.17 ms at 256^3 x 32).  Here the dcol
+// tile stays in LDS: a workgroup takes a 2 x 4 x 32 block of dx, computes T[q][tap] = dy[q] . w[:, tap] for the 4 x 6 x 34 voxels q of the block's
+// halo with MFMAs (A = w^T: lane <-> tap, B = dy rows straight from global memory: lane <-> voxel; bf16 results, as the dcol matrix was), and
+// every thread then sums the 27 entries T[p - (tap - 1)][tap] of its own output voxel.
+constexpr int kDZ = 2, kDY = 4, kDX = 32;
+constexpr int kDHZ = kDZ + 2, kDHY = kDY + 2, kDHX = kDX + 2, kDHN = kDHZ * kDHY * kDHX;      // 816 halo voxels
+constexpr int kTRow = 36;                                      // bf16 per T row: 32 taps + 4 (72-byte stride)
+
+template <int NT>
+__global__ __launch_bounds__(256, 2) void conv_c1_dx_kernel(const ConvC1Args a) {
+    constexpr int CO = 32 * NT, KS = CO / 16, NTILE = (kDHN + 31) / 32;
+    __shared__ __attribute__((aligned(16))) bf16 T[NTILE * 32 * kTRow];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+    int t = blockIdx.x;
+    const int x0 = (t % a.tiles_x) * kDX; t /= a.tiles_x;
+    const int y0 = (t % a.tiles_y) * kDY; t /= a.tiles_y;
+    const int z0 = (t % a.tiles_z) * kDZ;
+    const int b = t / a.tiles_z;
+    const bf16* dyb = reinterpret_cast<const bf16*>(a.dy) + (int64_t)b * a.OD * a.OH * a.OW * CO;
+    // w^T fragments: lane <-> tap r (rows 27.. of the [32][CO] operand are zero), k <-> output channel
+    const bf16* wt = reinterpret_cast<const bf16*>(a.w2d);
+    bf16x8 wf[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) wf[s] = *reinterpret_cast<const bf16x8*>(wt + r * CO + 16 * s + 8 * h);
+
+    auto fetch = [&](int tile, bf16x8 (&v)[KS]) {               // dy row of halo voxel 32 tile + r, this lane's halves
+        const int hv = 32 * tile + r;
+        const int hx = hv % kDHX, q = hv / kDHX, hy = q % kDHY, hz = q / kDHY;
+        const int sz = z0 - 1 + hz, sy = y0 - 1 + hy, sx = x0 - 1 + hx;
+        const bool ok = tile < NTILE && hv < kDHN && sz >= 0 && sz < a.OD && sy >= 0 && sy < a.OH && sx >= 0 && sx < a.OW;
+        const bf16* row = dyb + (((int64_t)(ok ? sz : 0) * a.OH + (ok ? sy : 0)) * a.OW + (ok ? sx : 0)) * CO + 8 * h;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            v[s] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            if (ok) v[s] = *reinterpret_cast<const bf16x8*>(row + 16 * s);
+        }
+    };
+    bf16x8 cur[KS], nxt[KS];
+    fetch(wave, cur);
+#pragma unroll 1
+    for (int tile = wave; tile < NTILE; tile += 4) {
+        fetch(tile + 4, nxt);
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) acc = mfma32(wf[s], cur[s], acc);
+        // rows = tap (registers), column = voxel (lane): four consecutive taps per register group -> T[voxel][tap]
+        bf16* trow = T + (32 * tile + r) * kTRow;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+            *reinterpret_cast<u32x2*>(trow + 8 * g + 4 * h) =
+                (u32x2){pack2(f2bf(acc[4 * g]), f2bf(acc[4 * g + 1])), pack2(f2bf(acc[4 * g + 2]), f2bf(acc[4 * g + 3]))};
+        }
+#pragma unroll
+        for (int s = 0; s < KS; ++s) cur[s] = nxt[s];
+    }
+    __syncthreads();
+    const int x = tid & 31, y = (tid >> 5) & 3, z = tid >> 7;
+    float sum = 0.f;
+#pragma unroll
+    for (int tap = 0; tap < kTaps; ++tap) {
+        const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+        sum += bf2f(T[(((z + 2 - kd) * kDHY + (y + 2 - kh)) * kDHX + (x + 2 - kw)) * kTRow + tap]);
+    }
+    const int oz = z0 + z, oy = y0 + y, ox = x0 + x;
+    if (oz < a.OD && oy < a.OH && ox < a.OW)
+        reinterpret_cast<bf16*>(a.y)[(((int64_t)b * a.OD + oz) * a.OH + oy) * a.OW + ox] = f2bf(sum);
 }
 
 // dw[e] = sum over the partials, fixed order: a block takes 16 consecutive outputs, its 256 threads = 16 outputs x 16 row groups
@@ -536,6 +609,18 @@ hipError_t conv_c1_dw_launch(ConvC1Args a, float* dw, hipStream_t st) {
     if (e != hipSuccess) return e;
     const int n = a.Cout * kTapPad;
     hipLaunchKernelGGL(conv_c1_dw_reduce_kernel, dim3((n + 15) / 16), dim3(256), 0, st, a.workspace, dw, n, parts);
+    return hipGetLastError();
+}
+
+// a.dy: [B][D][H][W][Cout]; a.w2d: w^T as [32 taps][Cout] bf16 (rows 27.. zero); a.y: dx [B][D][H][W]; a.SD.. = the volume extent
+hipError_t conv_c1_dx_launch(ConvC1Args a, hipStream_t st) {
+    if (!conv_c1_supported(a.Cout, 1) || a.stride != 1) return hipErrorInvalidValue;
+    a.OD = a.SD; a.OH = a.SH; a.OW = a.SW;
+    a.tiles_x = (a.OW + kDX - 1) / kDX; a.tiles_y = (a.OH + kDY - 1) / kDY; a.tiles_z = (a.OD + kDZ - 1) / kDZ;
+    const int64_t n = (int64_t)a.B * a.tiles_z * a.tiles_y * a.tiles_x;
+    if (n > 0x7fffffff) return hipErrorInvalidValue;
+    if (a.Cout == 32) hipLaunchKernelGGL(conv_c1_dx_kernel<1>, dim3((unsigned)n), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(conv_c1_dx_kernel<2>, dim3((unsigned)n), dim3(256), 0, st, a);
     return hipGetLastError();
 }
 

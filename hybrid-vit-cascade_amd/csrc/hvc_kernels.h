@@ -223,6 +223,7 @@ bool conv_c1_supported(int Cout, int stride);
 int conv_c1_dw_parts(int B, int SD, int SH, int SW, int stride);
 hipError_t conv_c1_fwd_launch(ConvC1Args a, hipStream_t st);
 hipError_t conv_c1_dw_launch(ConvC1Args a, float* dw, hipStream_t st);      // dw: [Cout][32] fp32, column 27 = bias gradient
+hipError_t conv_c1_dx_launch(ConvC1Args a, hipStream_t st);                // stride 1: dy in a.dy, w^T [32][Cout] in a.w2d, dx in a.y
 // Conv3d(CI -> CO, k3, s1, p1), CI, CO in {32, 64}, bf16 channels-last, through an LDS halo tile (conv_direct.hip).
 struct Conv3Args {
     const void* x;           // [B][D][H][W][CI]

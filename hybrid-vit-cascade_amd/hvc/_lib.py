@@ -47,6 +47,7 @@ SIGNATURES = {
     "hvc_conv_c1_fwd": (_i, [_p, _p, _p, _p] + [_i] * 6 + [_p]),
     "hvc_conv_c1_dw_workspace": (_i64, [_i] * 6),
     "hvc_conv_c1_dw": (_i, [_p, _p, _p, _p] + [_i] * 6 + [_p]),
+    "hvc_conv_c1_dx": (_i, [_p, _p, _p] + [_i] * 5 + [_p]),
     "hvc_conv3_halo": (_i, [_p, _p, _p, _p] + [_i] * 6 + [_p]),
     "hvc_conv_o1_fwd": (_i, [_p, _p, _p, _p, _i64, _i, _p]),
     "hvc_conv_o1_bwd_workspace": (_i64, [_i64, _i]),

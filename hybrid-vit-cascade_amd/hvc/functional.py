@@ -744,7 +744,10 @@ class ConvFn(torch.autograd.Function):
             dw = dwt.reshape(weight.shape) if ctx.needs_input_grad[1] else None
             dx = None
             if ctx.needs_input_grad[0]:
-                dx = _conv_dx_slabs(dyc.view(geom.B, *geom.out, cout), conv_weight_2d(weight, cdt, geom.Kp), geom, cdt)
+                if geom.stride == 1:
+                    dx = ops.conv_c1_dx(dyc.contiguous().view(geom.B, *geom.out, cout), conv_weight_2d(weight, cdt, geom.Kp), geom)
+                else:
+                    dx = _conv_dx_slabs(dyc.view(geom.B, *geom.out, cout), conv_weight_2d(weight, cdt, geom.Kp), geom, cdt)
                 if dx.dtype != xdt:
                     dx = dx.to(xdt)
             return dx, dw, (db if has_bias and ctx.needs_input_grad[2] else None), None, None, None, None

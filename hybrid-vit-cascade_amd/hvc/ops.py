@@ -461,6 +461,20 @@ def conv_c1_dw(x, dy, geom):
     return dw[:, :27], dw[:, 27]
 
 
+def conv_c1_dx(dy, w2d, geom):
+    """Input gradient of conv_c1_fwd at stride 1: dy (B, D, H, W, Cout) bf16, w2d (Cout, 32) bf16 -> dx (B, D, H, W, 1) bf16."""
+    _dev(dy, w2d)
+    cout = dy.shape[-1]
+    if not conv_c1_supported(geom, cout, dy.dtype) or geom.stride != 1 or not dy.is_contiguous() or dy.numel() != geom.M * cout \
+            or w2d.shape != (cout, 32) or w2d.dtype != torch.bfloat16:
+        raise ValueError("conv_c1_dx: contiguous bf16 dy of a stride-1 k3 p1 one-channel layer with 32 / 64 output channels expected")
+    wt = w2d.t().contiguous()
+    wt[27:].zero_()
+    dx = torch.empty((geom.B, *geom.src, 1), dtype=torch.bfloat16, device=dy.device)
+    check(_lib.load().hvc_conv_c1_dx(dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), geom.B, *geom.src, cout, _stream()), "hvc_conv_c1_dx")
+    return dx
+
+
 def conv3_halo_supported(geom, cout, dtype):
     """Conv3d(32 | 64 -> 32 | 64, k3, s1, p1) on bf16 activations: the layers hvc_conv3_halo covers."""
     return (dtype == torch.bfloat16 and geom.C in (32, 64) and cout in (32, 64) and geom.kernel == (3, 3, 3) and geom.pad == (1, 1, 1)

@@ -15,7 +15,7 @@ from . import functional as HF
 from . import ops
 
 STAGE_BACKEND = {
-    "voxel_embed_conv3d": "hip (implicit MFMA GEMM; first layer im2col + GEMM)",
+    "voxel_embed_conv3d": "hip (implicit MFMA GEMM; 1-channel first layer: streaming MFMA kernel, no patch matrix)",
     "voxel_embed_groupnorm_silu": "hip",
     "tokens_pos_embed": "hip (GEMM epilogue)",
     "head_layernorm": "hip",
@@ -27,7 +27,7 @@ STAGE_BACKEND = {
     "drr_projection_resize_l1_mse": "hip (fused resize + reduction)",
     "frequency_loss": "rocFFT + hip (fused magnitude / mask / L1)",
     "ssim_l1_loss": "hip",
-    "cascade_glue_conv_gn_gelu_upsample": "hip (implicit MFMA GEMM; single-channel layers slab-wise im2col above 2 GiB)",
+    "cascade_glue_conv_gn_gelu_upsample": "hip (1 -> 32|64 and C -> 1 layers: streaming kernels; 64 -> 32 k3: LDS halo tile; others implicit MFMA GEMM)",
 }
 
 

@@ -230,7 +230,7 @@ int hvc_col2im(const void* dcol, void* dsrc, int B, int C, int SD, int SH, int S
  *                  voxel-embed layer models/hybrid_vit_backbone.py:199.  x [B][SD][SH][SW], w2d [Cout][32] (tap = (kd*3 + kh)*3 + kw, columns
  *                  27..31 ignored), y / dy [B][OD][OH][OW][Cout], O = (S - 1)/stride + 1.  hvc_conv_c1_dw returns dw [Cout][32] fp32 whose
  *                  column 27 is the BIAS gradient (sum of dy over positions); workspace = hvc_conv_c1_dw_workspace(...) floats; partial sums
- *                  are added in a fixed order (bitwise reproducible).  The input gradient of these layers stays on hvc_gemm + hvc_col2im.
+ *                  are added in a fixed order (bitwise reproducible).  Input gradient: hvc_conv_c1_dx below (stride 1).
  *   hvc_conv_o1_*  nn.Conv3d(C, 1, 1) (model_progressive.py:266), C = 8 | 16 | 32 | 64 | 128, on the [M][C] view of the activations:
  *                  y[m] = bias + x[m] . w;  backward: dx[m][c] = dy[m] w[c] (dx may be NULL), dwb[0..C) = sum_m dy[m] x[m][c], dwb[C] = sum_m dy[m];
  *                  workspace = hvc_conv_o1_bwd_workspace(M, C) floats. */
@@ -244,6 +244,9 @@ int hvc_conv_c1_dw(const void* x, const void* dy, float* dw, float* workspace, i
  * weights, its input gradient.  wfrag: the weights pre-arranged in MFMA fragment order, [27 taps][CI/16][CO/32][64 lanes][8] bf16 with
  * element j of lane l = W[32 nt + (l & 31)][tap][16 ck + 8 (l >> 5) + j], W = (CO, tap = (kd*3 + kh)*3 + kw, CI). */
 int hvc_conv3_halo(const void* x, const void* wfrag, const float* bias, void* y, int B, int D, int H, int W, int CI, int CO, void* stream);
+/* Input gradient of hvc_conv_c1_fwd at stride 1: dy [B][D][H][W][Cout] bf16, wt = the weights TRANSPOSED, [32 taps][Cout] bf16 with rows 27..31
+ * zero, dx [B][D][H][W] bf16.  (Stride 2 - the direct model's first voxel-embed layer, whose input needs no gradient - stays on gemm + col2im.) */
+int hvc_conv_c1_dx(const void* dy, const void* wt, void* dx, int B, int D, int H, int W, int Cout, void* stream);
 int hvc_conv_o1_fwd(const void* x, const void* w, const float* bias, void* y, int64_t M, int C, void* stream);
 int64_t hvc_conv_o1_bwd_workspace(int64_t M, int C);
 int hvc_conv_o1_bwd(const void* x, const void* dy, const void* w, void* dx, float* dwb, float* workspace, int64_t M, int C, void* stream);
