@@ -42,8 +42,13 @@ constexpr int kQB = 128;    // rows per workgroup
 // on eight distinct 4-bank groups.  With the parts contiguous (64-byte steps) parts 0 / 2 and 1 / 3 met on the same banks:
 // rocprofv3 counted SQ_LDS_BANK_CONFLICT = 1 cycle per MFMA (134 M per launch at N = 32768, profiles/r01_pmc_attention_*) for this
 // kernel, all of it from these stores (the fragment reads of the Q / dO tiles are conflict-free, as in the forward and dQ kernels).
-constexpr int kLotPart = 32 + 8;           // 16-bit lots from one part's start to the next (32 keys + 16 bytes)
-constexpr int kLotStride = 4 * kLotPart;   // lots per tile row
+// (That is the eight-wavefront tile.  The four-wavefront tile keeps its parts contiguous and pads the ROW instead - 4 x 64 + 16 bytes: two
+// rows x four parts of a store group fall on banks 0 / 16 / 32 / 48 and 4 / 20 / 36 / 52, the next rows on + 8, + 12 - which takes the tile from
+// 40 to 34 KB: at d = 32 a workgroup then needs 51 KB and THREE of them share a CU, three wavefronts per SIMD: dK/dV -5 % without dropout, round 4.)
+template <int WAVES> struct LotTile {
+    static constexpr int PART = WAVES == 4 ? 32 : 32 + 8;            // 16-bit lots from one part's start to the next
+    static constexpr int ROW = WAVES == 4 ? 4 * 32 + 8 : 8 * (32 + 8);  // lots per tile row
+};
 constexpr float kRescaleLog2 = 6.f;   // deferred running-max update: P stays <= 2^6 between rescales
 constexpr float kRescaleSum = 1024.f; // 64-row forward: the same test on a half-row sum of 16 probabilities (16 * 2^6)
 
@@ -1371,9 +1376,9 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void attn_bwd_dq_ke
 // wavefronts 0-3, whose loader instructions also set them half a step behind 4-7), one barrier keeps the two wavefronts of a SIMD
 // in a fixed phase.
 template <typename T, int D, bool DROP, bool VEC, int WAVES = 4>
-__global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void attn_bwd_dkv_kernel(const AttnArgs a_in) {
+__global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? (D == 32 && sizeof(T) == 2 ? 3 : 2) : 1) void attn_bwd_dkv_kernel(const AttnArgs a_in) {
     constexpr int KB = 32 * WAVES;                  // keys per workgroup
-    constexpr int LS = WAVES * kLotPart;            // lots per tile row
+    constexpr int LP = LotTile<WAVES>::PART, LS = LotTile<WAVES>::ROW;      // lots per part / per tile row
     static_assert(WAVES == 4 || WAVES == 8, "4 or 8 wavefronts");
     AttnArgs a = a_in;
     a.seed_lo = seed_with_counter(a_in.seed_lo, a_in.seed_ctr);
@@ -1449,7 +1454,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void attn_bwd_dkv_k
             // keys KB kb + 32 part + 4 u .. + 3: 64-key tile (KB / 64) kb + (part >> 1), group j = 8 (part & 1) + u
             const uint32_t rk0 = drop_rowkey(a, bh, q), tadd = (uint32_t)((KB / 64) * kb + (part >> 1)) * kTileAdd;
             const uint32_t rk[2] = {(rk0 + tadd) ^ drop_grp_a(part & 1), ((rk0 ^ kGrpH) + tadd) ^ drop_grp_a(part & 1)};
-            uint32_t* dst = reinterpret_cast<uint32_t*>(lots + ((size_t)buf * kKT + ql) * LS + kLotPart * part);
+            uint32_t* dst = reinterpret_cast<uint32_t*>(lots + ((size_t)buf * kKT + ql) * LS + LP * part);
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const uint32_t m = rk[u & 1] ^ drop_grp_b(u >> 1);
@@ -1494,7 +1499,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void attn_bwd_dkv_k
         taddr[dt][1] = lds + ob;
     }
     const float* stat_lane = stat + 4 * h;                            // row constants of query rows 4h + {0..3} (+ 8g + 32qt)
-    const uint16_t* lots_lane = lots + 4 * h * LS + wave * kLotPart + r;
+    const uint16_t* lots_lane = lots + 4 * h * LS + wave * LP + r;
 
     auto step = [&](auto buf_tag, int t) {
         constexpr int buf = decltype(buf_tag)::value;
@@ -1664,7 +1669,7 @@ __global__ __launch_bounds__(256) void attn_dkv_reduce_kernel(const AttnArgs a) 
 template <typename T, int D>
 size_t fwd_lds_bytes() { return (size_t)2 * 2 * NSplit<T>::value * kKT * D * sizeof(bf16); }
 template <typename T, int D>
-size_t dkv_lds_bytes(bool drop, int waves = 4) { return fwd_lds_bytes<T, D>() + 2 * 2 * kKT * sizeof(float) + (drop ? 2 * kKT * waves * kLotPart * sizeof(uint16_t) : 0); }
+size_t dkv_lds_bytes(bool drop, int waves = 4) { return fwd_lds_bytes<T, D>() + 2 * 2 * kKT * sizeof(float) + (drop ? 2 * kKT * (waves == 4 ? LotTile<4>::ROW : LotTile<8>::ROW) * sizeof(uint16_t) : 0); }
 
 // Raises a kernel's dynamic-LDS limit once per (kernel, size): the attribute is sticky, and a driver call per launch would
 // also sit inside hipGraph captures of the training step.
@@ -1768,7 +1773,8 @@ hipError_t launch_bwd(const AttnArgs& a, hipStream_t st) {
         // 256-key workgroups of eight wavefronts once they fill every CU twice over (HVC_ATTN_BWD_WAVES=4 / 8 pins the form)
         constexpr bool CAN8 = sizeof(T) == 2 && VEC;
         const int pin = bwd_waves_pin();
-        const bool w8 = CAN8 && pin != 4 && (pin == 8 || (int64_t)((a.Nk + 255) / 256) * a.B * a.H >= 512);
+        // (d = 32: the four-wavefront form, three workgroups per CU - see LotTile - unless pinned)
+        const bool w8 = CAN8 && pin != 4 && (pin == 8 || (D != 32 && (int64_t)((a.Nk + 255) / 256) * a.B * a.H >= 512));
         const int KBh = w8 ? 256 : kQB;
         const int nkb = (a.Nk + KBh - 1) / KBh;
         const size_t lds = dkv_lds_bytes<T, D>(DROP, w8 ? 8 : 4) + extra_lds();
