@@ -1179,7 +1179,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const AttnArgs a) {
 // WAVES = 8 (round 3; chosen by launch_bwd): 256 query rows per workgroup, one workgroup per CU; the K / V tiles are staged once for eight
 // wavefronts (by wavefronts 0-3) - see attn_bwd_dkv_kernel.
 template <typename T, int D, bool DROP, bool VEC, int WAVES = 4>
-__global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void attn_bwd_dq_kernel(const AttnArgs a_in) {
+__global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? (D == 32 && sizeof(T) == 2 ? 3 : 2) : 1) void attn_bwd_dq_kernel(const AttnArgs a_in) {
     constexpr int QB = 32 * WAVES;
     AttnArgs a = a_in;
     a.seed_lo = seed_with_counter(a_in.seed_lo, a_in.seed_ctr);
@@ -1813,7 +1813,8 @@ hipError_t launch_bwd(const AttnArgs& a, hipStream_t st) {
         const size_t lds = fwd_lds_bytes<T, D>() + extra_lds();
         if constexpr (sizeof(T) == 2 && VEC) {
             const int pin = bwd_waves_pin();
-            if (pin != 4 && (pin == 8 || (int64_t)((a.Nq + 255) / 256) * a.B * a.H >= 512)) {
+            // (d = 32: the four-wavefront form at <= 168 registers, three workgroups per CU: -2.8 % same-box against the eight-wavefront form)
+            if (pin != 4 && (pin == 8 || (D != 32 && (int64_t)((a.Nq + 255) / 256) * a.B * a.H >= 512))) {
                 const int nqb = (a.Nq + 255) / 256;
                 auto k8 = attn_bwd_dq_kernel<T, D, DROP, VEC, 8>;
                 hipError_t e = set_lds(k8, lds);
