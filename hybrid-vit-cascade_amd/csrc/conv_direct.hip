@@ -235,15 +235,15 @@ __global__ __launch_bounds__(256) void conv_c1_dw_kernel(const ConvC1Args a) {
 
 // ---- input gradient of the Cin = 1 layers (stride 1):  dx[p] = sum_tap sum_co dy[p - (tap - 1)][co] w[co][tap] ---------------------------
 // Through hvc_gemm + hvc_col2im this was a [voxels][32] dcol matrix written and gathered again (0.67 + 2.17 ms at 256^3 x 32).  Here the dcol
-// tile stays in LDS: a workgroup takes a 2 x 4 x 32 block of dx, computes T[q][tap] = dy[q] . w[:, tap] for the 4 x 6 x 34 voxels q of the block's
+// tile stays in LDS: a workgroup takes a 2 x 8 x 32 block of dx, computes T[q][tap] = dy[q] . w[:, tap] for the 4 x 10 x 34 voxels q of the block's
 // halo with MFMAs (A = w^T: lane <-> tap, B = dy rows straight from global memory: lane <-> voxel; bf16 results, as the dcol matrix was), and
 // every thread then sums the 27 entries T[p - (tap - 1)][tap] of its own output voxel.
-constexpr int kDZ = 2, kDY = 4, kDX = 32;
-constexpr int kDHZ = kDZ + 2, kDHY = kDY + 2, kDHX = kDX + 2, kDHN = kDHZ * kDHY * kDHX;      // 816 halo voxels
-constexpr int kTRow = 36;                                      // bf16 per T row: 32 taps + 4 (72-byte stride)
+constexpr int kDZ = 2, kDY = 8, kDX = 32;                      // 512 outputs per workgroup (one per thread), halo read 2.66 x
+constexpr int kDHZ = kDZ + 2, kDHY = kDY + 2, kDHX = kDX + 2, kDHN = kDHZ * kDHY * kDHX;      // 1360 halo voxels
+constexpr int kTRow = 28;                                      // bf16 per T row: taps 0..27 (56-byte stride: 14 banks, conflict-free 8-byte stores)
 
 template <int NT>
-__global__ __launch_bounds__(256, 2) void conv_c1_dx_kernel(const ConvC1Args a) {
+__global__ __launch_bounds__(512, 2) void conv_c1_dx_kernel(const ConvC1Args a) {
     constexpr int CO = 32 * NT, KS = CO / 16, NTILE = (kDHN + 31) / 32;
     __shared__ __attribute__((aligned(16))) bf16 T[NTILE * 32 * kTRow];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
@@ -274,26 +274,27 @@ __global__ __launch_bounds__(256, 2) void conv_c1_dx_kernel(const ConvC1Args a) 
     bf16x8 cur[KS], nxt[KS];
     fetch(wave, cur);
 #pragma unroll 1
-    for (int tile = wave; tile < NTILE; tile += 4) {
-        fetch(tile + 4, nxt);
+    for (int tile = wave; tile < NTILE; tile += 8) {
+        fetch(tile + 8, nxt);
         f32x16 acc;
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[e] = 0.f;
 #pragma unroll
         for (int s = 0; s < KS; ++s) acc = mfma32(wf[s], cur[s], acc);
-        // rows = tap (registers), column = voxel (lane): four consecutive taps per register group -> T[voxel][tap]
+        // rows = tap (registers), column = voxel (lane): four consecutive taps per register group -> T[voxel][tap] (taps 28..31 do not exist)
         bf16* trow = T + (32 * tile + r) * kTRow;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-            *reinterpret_cast<u32x2*>(trow + 8 * g + 4 * h) =
-                (u32x2){pack2(f2bf(acc[4 * g]), f2bf(acc[4 * g + 1])), pack2(f2bf(acc[4 * g + 2]), f2bf(acc[4 * g + 3]))};
+            if (g < 3 || h == 0)
+                *reinterpret_cast<u32x2*>(trow + 8 * g + 4 * h) =
+                    (u32x2){pack2(f2bf(acc[4 * g]), f2bf(acc[4 * g + 1])), pack2(f2bf(acc[4 * g + 2]), f2bf(acc[4 * g + 3]))};
         }
 #pragma unroll
         for (int s = 0; s < KS; ++s) cur[s] = nxt[s];
     }
     __syncthreads();
-    const int x = tid & 31, y = (tid >> 5) & 3, z = tid >> 7;
+    const int x = tid & 31, y = (tid >> 5) & 7, z = tid >> 8;
     float sum = 0.f;
 #pragma unroll
     for (int tap = 0; tap < kTaps; ++tap) {
@@ -619,8 +620,8 @@ hipError_t conv_c1_dx_launch(ConvC1Args a, hipStream_t st) {
     a.tiles_x = (a.OW + kDX - 1) / kDX; a.tiles_y = (a.OH + kDY - 1) / kDY; a.tiles_z = (a.OD + kDZ - 1) / kDZ;
     const int64_t n = (int64_t)a.B * a.tiles_z * a.tiles_y * a.tiles_x;
     if (n > 0x7fffffff) return hipErrorInvalidValue;
-    if (a.Cout == 32) hipLaunchKernelGGL(conv_c1_dx_kernel<1>, dim3((unsigned)n), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(conv_c1_dx_kernel<2>, dim3((unsigned)n), dim3(256), 0, st, a);
+    if (a.Cout == 32) hipLaunchKernelGGL(conv_c1_dx_kernel<1>, dim3((unsigned)n), dim3(512), 0, st, a);
+    else hipLaunchKernelGGL(conv_c1_dx_kernel<2>, dim3((unsigned)n), dim3(512), 0, st, a);
     return hipGetLastError();
 }
 
