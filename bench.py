@@ -269,13 +269,14 @@ def main():
     graph_stream = None
     if distributed:
         ddp_kw = dict(device_ids=[device.index], gradient_as_bucket_view=True, bucket_cap_mb=32, static_graph=use_graph)
+        ddp_kw.update(json.loads(os.environ.get("HVC_DDP_KW", "{}")))      # experiments
         if use_graph:       # whole-step capture: DDP constructor, warm-up and capture on ONE side stream (hvc/graph.py: GraphedStep)
             graph_stream = torch.cuda.Stream(device=device)
             graph_stream.wait_stream(torch.cuda.current_stream(device))
             with torch.cuda.stream(graph_stream):
                 step_model = torch.nn.parallel.DistributedDataParallel(model, **ddp_kw)
             torch.cuda.current_stream(device).wait_stream(graph_stream)
-        else:               # eager: on the stream the steps run on (its AccumulateGrad nodes then sit on that stream too)
+        elif os.environ.get("HVC_NO_DDP_WRAP") != "1":               # eager: on the stream the steps run on (its AccumulateGrad nodes then sit on that stream too)
             step_model = torch.nn.parallel.DistributedDataParallel(model, **ddp_kw)
     xr, ct = make_batch(wl, rank, device)
     # identical initial weights on every rank (seed 0 in build(); DDP broadcasts rank 0's anyway), but each
@@ -311,6 +312,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
+    enqueue_s = time.perf_counter() - t0          # host time to ENQUEUE the K steps (the launch thread runs ahead of the GPU)
     barrier()
     elapsed = time.perf_counter() - t0
     ops.PROFILE, ops.PROFILE_ONLY = None, None
@@ -363,6 +365,7 @@ def main():
                        "loss": float(loss.item()), "stage_backends": stem.STAGE_BACKEND},
             "algorithmic_tflops_per_volume_fwd_bwd": 3 * fwd_flops / 1e12,
             "achieved_model_tflops_per_gpu": 3 * fwd_flops * wl["batch"] * args.steps / elapsed / 1e12,
+            "host_enqueue_ms_per_step": 1e3 * enqueue_s / args.steps,      # rank 0's launch thread; close to ms_per_step = host-bound
         }
         if prof:
             torch.cuda.synchronize()

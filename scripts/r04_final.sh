@@ -41,6 +41,9 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_c3 -o p -- pytho
 python3 scripts/prof_summary.py $(find $O/prof_c3 -name "*kernel_stats.csv") 4 40 > $O/r04_cascade_stage3_256_rocprofv3_kernel_stats.txt
 rm -rf $O/prof_c3
 tail -3 $O/cascade3_steps.log
+python3 scripts/cascade_fullsize.py 3 1 6 2>&1 | grep -v amdgpu.ids > $O/cascade3_plain_steps.log || exit 30
+python3 scripts/cascade_fullsize.py 2 2 6 2>&1 | grep -v amdgpu.ids > $O/cascade2_plain_steps.log || exit 31
+python3 scripts/glue_layers.py 256 3 2>&1 | grep -v amdgpu.ids > $O/glue_after.log || exit 32
 echo "[7] default bench line (with cpu_baseline and the other resolutions), and the same with --ddp (RCCL, world size 1)"; date
 python3 bench.py > $O/bench_default.json 2> $O/bench_default.err || exit 27
 python3 bench.py --ddp --no-cpu-baseline --no-extra > $O/bench_ddp_rccl_world1.json 2> $O/bench_ddp.err || exit 28

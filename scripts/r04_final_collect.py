@@ -12,8 +12,8 @@ HEAD = {
     "r04_gemm_vs_hipblaslt.txt": "# scripts/gemm_vs_blas.py, round-4 closing build (GEMM kernel unchanged since round 3 apart from hvc_set_option), plain block shapes, hvc_gemm vs torch.mm (hipBLASLt)\n",
     "r04_gemm_shapes_direct128.txt": "# scripts/gemm_shapes.py direct128, round-4 closing build: every ops.gemm shape of one 128^3 train step\n",
     "r04_attention_pipelined_forward_ab.txt": "# scripts/attn_pipe_ab.py fwd, round-4 closing build: same-box alternating A/B of attn_fwdp_kernel (HVC_ATTN_PIPE=1) against the phase-separated attn_fwd2_kernel (=0); 'pipelined, 4-wavefront workgroups' = HVC_ATTN_FWD_WAVES=4 (the form d = 32 takes by default)\n",
-    "r04_attention_shapes.txt": "# scripts/attn_shapes.py, round-4 closing build: HIP-event minima of the attention kernels on the BASELINE shapes\n",
-    "r04_cascade_stage3_256_rocprofv3_kernel_stats.txt": "# rocprofv3 --kernel-trace --stats -- python3 scripts/cascade_fullsize.py 3 1 4 (cascade stage 3 at 256^3, B = 1, checkpoint policy auto = off; see r04_cascade_stage3_256_steps.log)\n",
+    "r04_attention_shapes.txt": "# scripts/attn_shapes.py, round-4 closing build: HIP-event minima of the attention kernels on the BASELINE shapes (d = 32: dK/dV and dQ as four-wavefront workgroups, three per CU)\n",
+    "r04_cascade_stage3_256_rocprofv3_kernel_stats.txt": "# rocprofv3 --kernel-trace --stats -- python3 scripts/cascade_fullsize.py 3 1 4 (cascade stage 3 at 256^3, B = 1, checkpoint policy auto = off; see r04_cascade_stage3_256_steps.log) - closing build: streaming single-channel / halo-tile convolutions (DESIGN 5.3.1), d = 32 dK/dV and dQ three workgroups per CU (5.1.5)\n",
 }
 for wl in ("direct128", "direct64", "direct256"):
     HEAD[f"r04_bench_{wl}_rocprofv3_kernel_stats.txt"] = B % (wl, wl)
@@ -24,7 +24,16 @@ for name, head in HEAD.items():
     open(os.path.join(DST, name), "w").write(head + body)
 for wl in ("direct128", "direct64", "direct256"):
     shutil.copy(os.path.join(SRC, f"bench_{wl}_under_rocprof.json"), os.path.join(DST, f"r04_bench_{wl}_under_rocprof.json"))
-shutil.copy(os.path.join(SRC, "cascade3_steps.log"), os.path.join(DST, "r04_cascade_stage3_256_steps.log"))
+with open(os.path.join(DST, "r04_cascade_stage3_256_steps.log"), "w") as f:
+    f.write("# scripts/cascade_fullsize.py 3 1 6, round-4 closing build (no profiler):\n" + open(os.path.join(SRC, "cascade3_plain_steps.log")).read())
+    f.write("# the same under rocprofv3 --kernel-trace (r04_cascade_stage3_256_rocprofv3_kernel_stats.txt):\n"
+            + "".join(l for l in open(os.path.join(SRC, "cascade3_steps.log")) if "amdgpu.ids" not in l))
+    f.write("# scripts/cascade_fullsize.py 2 2 6 (stage 2 at 128^3, B = 2: BASELINE configs #4 geometry), same build:\n" + open(os.path.join(SRC, "cascade2_plain_steps.log")).read())
+glue = open(os.path.join(DST, "r04_glue_layers_256.txt")).read()
+i0, i1 = glue.index("# AFTER (closing build"), glue.index("#\n# 64 -> 32 layer, versions of conv3_halo_kernel")
+glue = (glue[:i0] + "# AFTER (closing build: conv_c1_fwd / conv_c1_dw / conv_c1_dx, conv3_halo (forward and input gradient of the 64 -> 32 layer), conv_o1_fwd / _bwd,\n"
+        "# division-free GroupNorm apply)\n" + open(os.path.join(SRC, "glue_after.log")).read() + glue[i1:])
+open(os.path.join(DST, "r04_glue_layers_256.txt"), "w").write(glue)
 for a, b in (("bench_default.json", "r04_bench_default.json"), ("bench_ddp_rccl_world1.json", "r04_bench_ddp_rccl_world1.json"),
              ("bench_direct64_ddp_graph.json", "r04_bench_direct64_ddp_rccl_world1_hipgraph.json")):
     shutil.copy(os.path.join(SRC, a), os.path.join(DST, b))

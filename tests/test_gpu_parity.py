@@ -1530,6 +1530,8 @@ def test_conv_implicit_gemm_vs_fp64_and_im2col(cfg, dtype):
     (1, 32, 64, 3, 1, (4, 6, 33)),       # (hvc_conv3_halo), forward and - mirrored taps, swapped channels - input gradient; ragged blocks
     (1, 32, 32, 3, 1, (2, 8, 32)),       # exactly one block
     (1, 64, 64, 3, 1, (3, 5, 70)),
+    (1, 1, 32, 3, 1, (24, 20, 72)),      # several blocks along every axis (interior blocks with full halos)
+    (1, 64, 32, 3, 1, (10, 20, 72)),
 ])
 def test_conv_single_channel_streaming_kernels_vs_fp64_and_gemm_path(cfg):
     """The single-channel layers of the cascade glue as streaming kernels (hvc_conv_c1_fwd / _dw, hvc_conv_o1_fwd / _bwd) against F.conv3d
