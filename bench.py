@@ -72,12 +72,17 @@ def make_batch(workload, rank, device):
     return xr.to(device), ct.to(device)
 
 
-def train_step(model, params, crit, opt, xr, ct):
-    opt.zero_grad(set_to_none=True)
+def train_step(model, params, crit, opt, xr, ct, reducer=None):
+    if reducer is not None:
+        reducer.zero_grad()                   # gradients are views of the reducer's flat buffer: zeroed, not dropped
+    else:
+        opt.zero_grad(set_to_none=True)
     with torch.autocast("cuda", dtype=torch.bfloat16):
         pred = model(xr)
         loss = crit(pred.float(), ct)["total_loss"]
     loss.backward()
+    if reducer is not None:
+        reducer.finish()                      # the bucketed all-reduces were launched from inside backward; join them
     torch.nn.utils.clip_grad_norm_(params, 1.0)
     opt.step()
     return loss
@@ -213,6 +218,9 @@ def main():
     ap.add_argument("--graph", default="auto", choices=("auto", "on", "off"),
                     help="replay the step as one captured hipGraph (auto: for the launch-bound direct64 workload, single GPU)")
     ap.add_argument("--no-extra", action="store_true", help="skip the short 64^3 / 256^3 runs reported under other_resolutions")
+    ap.add_argument("--torch-ddp", action="store_true",
+                    help="eager multi-rank steps through torch DistributedDataParallel instead of hvc.reducer.BucketedGradReducer "
+                         "(A/B: DDP's per-parameter hooks cost ~19 ms of host time per 128^3 step)")
     ap.add_argument("--ddp", action="store_true",
                     help="with --gpus 1: still initialise the nccl (= RCCL) process group (world size 1) and wrap the model in DDP, so that "
                          "the multi-GPU code path - RCCL init, bucketed all-reduce hooks on the HIP autograd Functions - runs on one GPU")
@@ -247,10 +255,22 @@ def main():
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
         backend = os.environ.get("HVC_DIST_BACKEND", "nccl")
-        if backend == "nccl":
-            torch.distributed.init_process_group("nccl", device_id=device)   # RCCL over xGMI
-        else:
-            torch.distributed.init_process_group(backend)
+        # RCCL prints a version banner on STDOUT when its first communicator comes up; stdout carries the one JSON line, so file
+        # descriptor 1 points at stderr until the communicator exists (a barrier forces it)
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if backend == "nccl":
+                torch.distributed.init_process_group("nccl", device_id=device)   # RCCL over xGMI
+            else:
+                torch.distributed.init_process_group(backend)
+            torch.distributed.barrier()
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
 
     from hvc import ops, stem
     wl = WORKLOADS[args.workload]
@@ -267,17 +287,23 @@ def main():
     fwd_flops, geom = fwd_flops_per_volume(model)
     step_model = model
     graph_stream = None
+    reducer = None
     if distributed:
         ddp_kw = dict(device_ids=[device.index], gradient_as_bucket_view=True, bucket_cap_mb=32, static_graph=use_graph)
-        ddp_kw.update(json.loads(os.environ.get("HVC_DDP_KW", "{}")))      # experiments
         if use_graph:       # whole-step capture: DDP constructor, warm-up and capture on ONE side stream (hvc/graph.py: GraphedStep)
             graph_stream = torch.cuda.Stream(device=device)
             graph_stream.wait_stream(torch.cuda.current_stream(device))
             with torch.cuda.stream(graph_stream):
                 step_model = torch.nn.parallel.DistributedDataParallel(model, **ddp_kw)
             torch.cuda.current_stream(device).wait_stream(graph_stream)
-        elif os.environ.get("HVC_NO_DDP_WRAP") != "1":               # eager: on the stream the steps run on (its AccumulateGrad nodes then sit on that stream too)
+        elif args.torch_ddp:   # eager: on the stream the steps run on (its AccumulateGrad nodes then sit on that stream too)
             step_model = torch.nn.parallel.DistributedDataParallel(model, **ddp_kw)
+        else:
+            # eager steps: bucketed all-reduce of a flat gradient buffer driven by one autograd hook per bucket (hvc/reducer.py) - DDP's
+            # contract and overlap without its per-parameter host work, which makes the 128^3 step host-bound
+            from hvc.reducer import BucketedGradReducer, broadcast_module_state
+            broadcast_module_state(model)
+            reducer = BucketedGradReducer(params, bucket_bytes=32 << 20)
     xr, ct = make_batch(wl, rank, device)
     # identical initial weights on every rank (seed 0 in build(); DDP broadcasts rank 0's anyway), but each
     # data-parallel replica draws its own dropout seeds, as the reference's per-process generators do
@@ -289,7 +315,7 @@ def main():
         torch.cuda.synchronize()
 
     def eager_step():
-        return train_step(step_model, params, crit, opt, xr, ct)
+        return train_step(step_model, params, crit, opt, xr, ct, reducer)
     step = eager_step
     if use_graph:
         from hvc.graph import GraphedStep
@@ -406,7 +432,8 @@ def main():
             out["rccl_ranks"] = torch.distributed.get_world_size()
             out["dist_backend"] = torch.distributed.get_backend()
             out["ddp"] = {"bucket_cap_mb": 32, "gradient_as_bucket_view": True, "static_graph": bool(use_graph),
-                          "captured_in_hipgraph": bool(use_graph)}
+                          "captured_in_hipgraph": bool(use_graph),
+                          "gradient_exchange": reducer.describe() if reducer is not None else "torch DistributedDataParallel"}
             if rank_ms is not None:
                 out["rank_ms_per_step"] = {"min": min(rank_ms), "max": max(rank_ms)}
             out["ipc_env"] = {"HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")}

@@ -1352,6 +1352,77 @@ def test_ddp_two_ranks_on_the_hip_path(tmp_path):
         assert torch.equal(r0["params"][k], r1["params"][k]), k
 
 
+def _reducer_gpu_worker(rank, world, port, out_dir):
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    sys.path.insert(0, os.path.join(root, "hybrid-vit-cascade_amd"))
+    from direct_regression import train_direct_4gpu as T
+    from direct_regression.model_direct import DirectCTRegression, DirectRegressionLoss
+    from hvc import synthetic
+    from hvc.reducer import BucketedGradReducer, broadcast_module_state
+    T.setup_ddp(rank, world, backend="gloo", port=str(port))       # both ranks share cuda:0; gloo moves the buckets
+    torch.cuda.set_device(0)
+    cfg = dict(volume_size=(16, 16, 16), xray_img_size=64, voxel_dim=64, vit_depth=2, num_heads=2, xray_feature_dim=32)
+    torch.manual_seed(rank)                        # different initial weights per rank: the broadcast must align them
+    model = DirectCTRegression(**cfg).cuda(0).train()
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    broadcast_module_state(model)
+    crit = DirectRegressionLoss()
+    xr, ct = synthetic.batch(10 * rank, 2, cfg["volume_size"], cfg["xray_img_size"], device="cuda:0")
+    params = [p for p in model.parameters() if p.requires_grad]
+    names = [k for k, p in model.named_parameters() if p.requires_grad]
+    red = BucketedGradReducer(params, bucket_bytes=256 * 1024, check=True)
+    opt = torch.optim.AdamW(params, lr=1e-3, weight_decay=0.01)
+    local, reduced = [], []
+    for it in range(3):
+        # the rank's own gradient of this step, for the mean check (no reduction: plain autograd.grad)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            loss = crit(model(xr), ct)["total_loss"]
+        g = torch.autograd.grad(loss, params, allow_unused=True)
+        local.append({k: (None if t is None else t.detach().float().cpu()) for k, t in zip(names, g)})
+        for m in model.modules():                 # the probe pass moved the BatchNorm running statistics: irrelevant to the gradients
+            pass
+        red.zero_grad()
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            loss = crit(model(xr), ct)["total_loss"]
+        loss.backward()
+        red.finish()
+        reduced.append({k: p.grad.detach().float().cpu().clone() for k, p in zip(names, params)})
+        torch.nn.utils.clip_grad_norm_(params, 1.0)
+        opt.step()
+    torch.save({"local": local, "reduced": reduced, "params": {k: v.detach().cpu() for k, v in model.state_dict().items()},
+                "desc": red.describe(), "order_head": [names[i] for i in red.order[:3]]}, os.path.join(out_dir, f"rank{rank}.pt"))
+    T.cleanup_ddp()
+
+
+@pytest.mark.timeout(600)
+def test_bucketed_reducer_two_ranks_on_the_hip_path(tmp_path):
+    """hvc.reducer.BucketedGradReducer (what `bench.py --gpus N` runs eagerly: one autograd hook per bucket instead of DDP's one per
+    parameter) with the HIP autograd Functions: two processes on cuda:0 over gloo, three optimizer steps in check mode - every step's
+    reduced gradients are the mean of the ranks' local ones (discovery step and bucketed steps alike), replicas stay identical."""
+    import torch.multiprocessing as mp
+    world, port = 2, 29537
+    mp.spawn(_reducer_gpu_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = (torch.load(tmp_path / f"rank{r}.pt") for r in range(world))
+    assert r0["desc"]["buckets"] >= 2, r0["desc"]
+    for step in range(3):
+        for k in r0["reduced"][step]:
+            a, b = r0["local"][step][k], r1["local"][step][k]
+            if a is None:
+                continue
+            mean_local = (a + b) / 2
+            assert torch.allclose(r0["reduced"][step][k], mean_local, rtol=2e-3, atol=1e-6), (step, k)
+            assert torch.equal(r0["reduced"][step][k], r1["reduced"][step][k]), (step, k)
+    for k in r0["params"]:
+        if "running_" in k or "num_batches" in k:
+            continue
+        assert torch.equal(r0["params"][k], r1["params"][k]), k
+
+
 @pytest.fixture(params=["implicit", "im2col"])
 def conv_path(request):
     """Runs a convolution test on both data paths: patches gathered inside the GEMM (C % 8 == 0) and im2col + GEMM + col2im."""
@@ -1793,7 +1864,7 @@ def _run_bench(args, timeout=850):
 @pytest.mark.timeout(1100)
 def test_bench_runs_the_ddp_path_over_rccl_on_one_gpu():
     """`bench.py --gpus 1 --ddp`: the multi-GPU code path on the one GPU of the test box - init_process_group("nccl") (= RCCL),
-    DDP bucket views and all-reduce hooks over the HIP autograd Functions, barrier + max-over-ranks timing - so that the first
+    the bucketed gradient all-reduce (hvc.reducer) hooked into the HIP autograd Functions' backward, barrier + max-over-ranks timing - so that the first
     RCCL initialisation does not happen on the driver's 8-GPU run (reference: direct_regression/train_direct_4gpu.py:25-37, :146).
     A world-size-1 all-reduce moves no data over xGMI: same-box runs differ by 0.5 - 1.5 % (profiles/r04_bench_ddp_rccl_world1.json), one box in
     five showed 5 % (RCCL's world-size-1 copy kernels next to the attention kernels); the bound is 8 %, the measured value goes to the margins log."""
@@ -1804,6 +1875,8 @@ def test_bench_runs_the_ddp_path_over_rccl_on_one_gpu():
     plain = min(runs[1::2], key=lambda d: d["ms_per_step"])
     assert ddp["dist_backend"] == "nccl" and ddp["rccl_ranks"] == 1 and ddp["nccl_version"], ddp
     assert ddp["ddp"]["gradient_as_bucket_view"] and ddp["n_gpus"] == 1
+    assert "BucketedGradReducer" in ddp["ddp"]["gradient_exchange"]["reducer"] and ddp["ddp"]["gradient_exchange"]["buckets"] >= 2
+    assert ddp["host_enqueue_ms_per_step"] < 0.9 * ddp["ms_per_step"], "the launch thread must stay ahead of the GPU"
     assert "dist_backend" not in plain
     assert "after the timed region" in ddp["roofline"]["measured_over"] and "timed steps" in plain["roofline"]["measured_over"]
     rel = abs(ddp["ms_per_step"] - plain["ms_per_step"]) / plain["ms_per_step"]
