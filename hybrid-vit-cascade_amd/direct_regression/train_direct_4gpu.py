@@ -70,10 +70,14 @@ def _on_device(dataloader, rank):
 
 
 def train_step(model, criterion, optimizer, scaler, xrays, ct_volume, gradient_clip, autocast_device="cuda",
-               autocast_dtype=torch.bfloat16):
+               autocast_dtype=torch.bfloat16, reducer=None):
     """One optimisation step (reference train_epoch body, :62-75).  Returns the loss dict.
-    autocast_dtype=None runs the step in fp32 (split-bf16 MFMA products), the mode the parity fixture uses."""
-    optimizer.zero_grad(set_to_none=True)
+    autocast_dtype=None runs the step in fp32 (split-bf16 MFMA products), the mode the parity fixture uses.
+    reducer: an hvc.reducer.BucketedGradReducer over the (unwrapped) model's parameters instead of a DDP-wrapped model."""
+    if reducer is not None:
+        reducer.zero_grad()
+    else:
+        optimizer.zero_grad(set_to_none=True)
     with torch.autocast(autocast_device, dtype=autocast_dtype or torch.bfloat16, enabled=autocast_dtype is not None):
         with HF.trace_range("forward"):
             predicted = model(xrays)
@@ -83,6 +87,8 @@ def train_step(model, criterion, optimizer, scaler, xrays, ct_volume, gradient_c
     if scaler is not None:
         with HF.trace_range("backward"):
             scaler.scale(total_loss).backward()
+            if reducer is not None:
+                reducer.finish()
         with HF.trace_range("optimizer"):
             scaler.unscale_(optimizer)
             torch.nn.utils.clip_grad_norm_(model.parameters(), gradient_clip)
@@ -91,6 +97,8 @@ def train_step(model, criterion, optimizer, scaler, xrays, ct_volume, gradient_c
     else:
         with HF.trace_range("backward"):
             total_loss.backward()
+            if reducer is not None:
+                reducer.finish()
         with HF.trace_range("optimizer"):
             torch.nn.utils.clip_grad_norm_(model.parameters(), gradient_clip)
             optimizer.step()
@@ -106,7 +114,8 @@ def train_epoch(model, dataloader, criterion, optimizer, scaler, rank, epoch, co
     for batch_idx, batch in enumerate(_on_device(dataloader, rank)):
         xrays = batch["drr_stacked"].cuda(rank, non_blocking=True)
         ct_volume = batch["ct_volume"].cuda(rank, non_blocking=True)
-        loss_dict = train_step(model, criterion, optimizer, scaler, xrays, ct_volume, config["training"]["gradient_clip"])
+        loss_dict = train_step(model, criterion, optimizer, scaler, xrays, ct_volume, config["training"]["gradient_clip"],
+                               reducer=config.get("_grad_reducer"))
         sums["total"] += loss_dict["total_loss"].item()
         sums["l1"] += loss_dict["l1_loss"].item()
         sums["ssim"] += loss_dict["ssim_loss"].item()
@@ -141,7 +150,8 @@ def save_checkpoint(path, epoch, model, optimizer, scheduler, val_psnr, best_psn
     """The reference's checkpoint dict (direct_regression/train_direct_4gpu.py:277-298): unwrapped model state, optimizer,
     scheduler, epoch, val_psnr, best_psnr, config."""
     torch.save({"epoch": epoch, "model_state_dict": model.state_dict(), "optimizer_state_dict": optimizer.state_dict(),
-                "scheduler_state_dict": scheduler.state_dict(), "val_psnr": val_psnr, "best_psnr": best_psnr, "config": config}, path)
+                "scheduler_state_dict": scheduler.state_dict(), "val_psnr": val_psnr, "best_psnr": best_psnr,
+                "config": {k: v for k, v in config.items() if not k.startswith("_")}}, path)      # (run-time objects, e.g. the gradient reducer, stay out)
 
 
 def load_checkpoint(path, model, optimizer, scheduler, map_location):
@@ -168,7 +178,15 @@ def train_ddp(rank, world_size, config, resume_from=None, synthetic=False):
     if rank == 0:
         total = sum(p.numel() for p in model.parameters())
         print(f"\nModel parameters: {total:,} ({total / 1e6:.2f}M)")
-    ddp_model = wrap_ddp(model, [rank]) if dist.is_initialized() else model
+    # mi355x.grad_exchange: "ddp" (default: torch DistributedDataParallel, as the reference) | "bucketed" (hvc.reducer: one autograd hook per
+    # bucket - DDP's per-parameter hooks make the 128^3 step host-bound; module buffers are broadcast once, not every forward)
+    ddp_model = model
+    if dist.is_initialized() and config.get("mi355x", {}).get("grad_exchange", "ddp") == "bucketed":
+        from hvc.reducer import BucketedGradReducer, broadcast_module_state
+        broadcast_module_state(model)
+        config["_grad_reducer"] = BucketedGradReducer([p for p in model.parameters() if p.requires_grad], bucket_bytes=BUCKET_CAP_MB << 20)
+    elif dist.is_initialized():
+        ddp_model = wrap_ddp(model, [rank])
     tr = config["training"]
     optimizer = torch.optim.AdamW(ddp_model.parameters(), lr=tr["learning_rate"], weight_decay=tr["weight_decay"], fused=True)
     scheduler = torch.optim.lr_scheduler.CosineAnnealingLR(optimizer, T_max=tr["num_epochs"], eta_min=1e-6)
