@@ -8,14 +8,15 @@ bucket size / static_graph / broadcast_buffers settings) against a 54 ms GPU ste
 GPU and every rank of an N > 1 job loses 5 - 9 % to the host, before a byte moves over xGMI.
 
 BucketedGradReducer keeps DDP's contract and its overlap, with the host work of a handful of hooks:
-  * all gradients live in ONE flat fp32 buffer (`p.grad` are views, like DDP's gradient_as_bucket_view), laid out in the order
-    in which the backward pass produces them, so a bucket is a contiguous slice;
+  * all gradients end up in ONE flat fp32 buffer laid out in the order in which the backward pass produces them, so a bucket is a
+    contiguous slice; the backward pass itself hands every parameter a fresh gradient tensor (no per-parameter accumulate kernel, as
+    bucket views cost), and the bucket's hook gathers its members with one multi-tensor copy and points their `.grad` at the slots;
   * the first backward (per-parameter hooks, once) records that order; from then on only the LAST parameter of each bucket
     carries a hook, which all-reduces the bucket's slice on a side stream (RCCL over xGMI; AVG);
   * finish() - after backward, before clipping / optimizer.step - joins the side stream.
 The step must be static (same parameters receive gradients in the same order every step), which the reference's training loops
 are; `check=True` keeps the per-parameter hooks and asserts the order on every step (tests).
-Gradients must stay allocated: use reducer.zero_grad() instead of optimizer.zero_grad(set_to_none=True).
+Use reducer.zero_grad() instead of optimizer.zero_grad(): it drops the gradients (set-to-none semantics).
 """
 import torch
 import torch.distributed as dist
@@ -35,7 +36,7 @@ class BucketedGradReducer:
         self.device = dev
         self.comm_stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
         self._order, self._hooks, self._work, self._launched = [], [], [], set()
-        self._buckets = None                    # [(start, end, sentinel parameter index)] once the order is known
+        self._buckets = None                    # [(start, end, [member parameter indices])] once the arrival order is known
         self._fired = set()
         self._layout(list(range(len(self.params))))
         for i, p in enumerate(self.params):     # discovery: one backward with a hook on every parameter
@@ -43,14 +44,14 @@ class BucketedGradReducer:
 
     # ---- layout ---------------------------------------------------------------------------------------------------------------
     def _layout(self, order):
-        """Flat buffer with the parameters' gradients in `order`; p.grad become views of it (contents are not carried over)."""
+        """Flat buffer holding the gradients of the parameters in `order` (zeros until a step writes them)."""
         self.order = order
         sizes = [self.params[i].numel() for i in order]
         self.flat = torch.zeros(sum(sizes), dtype=self.params[0].dtype, device=self.device)
-        self.offsets, off = {}, 0
+        self.offsets, self.views, off = {}, {}, 0
         for i, n in zip(order, sizes):
             self.offsets[i] = (off, off + n)
-            self.params[i].grad = self.flat[off:off + n].view_as(self.params[i])
+            self.views[i] = self.flat[off:off + n].view_as(self.params[i])
             off += n
 
     def _make_discovery_hook(self, i):
@@ -61,8 +62,7 @@ class BucketedGradReducer:
     def _make_bucket_hook(self, b):
         def hook(_p):
             if self.check:
-                start, end, _ = self._buckets[b]
-                missing = [i for i in self.order if start <= self.offsets[i][0] < end and i not in self._fired]
+                missing = [i for i in self._buckets[b][2] if i not in self._fired]
                 if missing:
                     raise RuntimeError(f"BucketedGradReducer: bucket {b} closed before the gradients of parameters {missing} arrived "
                                        "(the step is not static)")
@@ -70,46 +70,53 @@ class BucketedGradReducer:
         return hook
 
     def _rebuild(self):
-        """After the discovery backward: lay the buffer out in arrival order, cut it into buckets, keep one hook per bucket."""
+        """After the discovery backward: lay the buffer out in arrival order, cut it into buckets, keep one hook per bucket.
+        Parameters that received no gradient get no slot: their .grad stays None, as without any reducer."""
         seen = list(dict.fromkeys(self._order))
-        rest = [i for i in range(len(self.params)) if i not in set(seen)]       # parameters that received no gradient: at the end
         for h in self._hooks:
             h.remove()
         self._hooks = []
-        self._layout(seen + rest)
+        self._layout(seen)
         esize = self.flat.element_size()
-        buckets, start, last = [], 0, None
+        buckets, start, members = [], 0, []
         for i in seen:
-            last = i
+            members.append(i)
             end = self.offsets[i][1]
             if (end - start) * esize >= self.bucket_bytes:
-                buckets.append((start, end, i))
-                start, last = end, None
-        total = self.flat.numel()
-        if start < total:
-            # the tail (incl. parameters without gradients) closes with the last parameter that does arrive - or, if none is left
-            # in it, it is reduced by finish()
-            buckets.append((start, total, last))
+                buckets.append((start, end, members))
+                start, members = end, []
+        if members:
+            buckets.append((start, self.flat.numel(), members))
         self._buckets = buckets
         if self.check:                          # (registered first: a parameter's hooks run in registration order)
             for i in seen:
                 self._hooks.append(self.params[i].register_post_accumulate_grad_hook(lambda _p, i=i: self._fired.add(i)))
-        for b, (_, _, sentinel) in enumerate(buckets):
-            if sentinel is not None:
-                self._hooks.append(self.params[sentinel].register_post_accumulate_grad_hook(self._make_bucket_hook(b)))
+        for b, (_, _, mem) in enumerate(buckets):   # the bucket closes with the gradient that arrives last in it
+            self._hooks.append(self.params[mem[-1]].register_post_accumulate_grad_hook(self._make_bucket_hook(b)))
 
     # ---- per step -------------------------------------------------------------------------------------------------------------
     def zero_grad(self):
-        """Call instead of optimizer.zero_grad(): gradients stay allocated (views of the flat buffer)."""
+        """Call instead of optimizer.zero_grad(): the gradients are dropped (the backward pass hands each parameter a fresh tensor, no
+        accumulate kernel), and each bucket's hook gathers them into its slice of the flat buffer, which p.grad then views."""
         if self._buckets is None and self._order:
             self._rebuild()                     # the discovery step is over: its gradients have been consumed
         self._order, self._fired, self._launched = [], set(), set()
-        self.flat.zero_()
-        for i in self.order:                    # an optimizer or a user may have dropped them (set_to_none): re-attach
-            p = self.params[i]
-            if p.grad is None or p.grad.data_ptr() != self.flat.data_ptr() + self.offsets[i][0] * self.flat.element_size():
-                a, b = self.offsets[i]
-                p.grad = self.flat[a:b].view_as(p)
+        for p in self.params:
+            p.grad = None
+
+    def _gather(self, members):
+        """The members' freshly produced gradients -> their slots (one multi-tensor copy); p.grad become the slots."""
+        src, dst = [], []
+        for i in members:
+            g = self.params[i].grad
+            if g is None:
+                self.views[i].zero_()           # no gradient this step (possible only when the step is not static)
+            elif g.data_ptr() != self.views[i].data_ptr():
+                src.append(g)
+                dst.append(self.views[i])
+            self.params[i].grad = self.views[i]
+        if src:
+            torch._foreach_copy_(dst, src)
 
     def _all_reduce(self, view):
         if self.backend == "nccl":
@@ -118,8 +125,9 @@ class BucketedGradReducer:
         return (work, view)
 
     def _launch(self, b):
-        start, end, _ = self._buckets[b]
+        start, end, members = self._buckets[b]
         self._launched.add(b)
+        self._gather(members)
         view = self.flat[start:end]
         if self.comm_stream is not None:
             self.comm_stream.wait_stream(torch.cuda.current_stream(self.device))
@@ -131,7 +139,9 @@ class BucketedGradReducer:
     def finish(self):
         """After backward: reduce what no hook has (the discovery step: everything) and make the gradients visible to the caller's stream."""
         if self._buckets is None:
-            self._launch_all()
+            self._buckets = [(0, self.flat.numel(), list(self.order))]
+            self._launch(0)
+            self._buckets = None
         else:
             for b in range(len(self._buckets)):
                 if b not in self._launched:
@@ -145,11 +155,11 @@ class BucketedGradReducer:
         self._work = []
         if self.comm_stream is not None:
             torch.cuda.current_stream(self.device).wait_stream(self.comm_stream)
-
-    def _launch_all(self):
-        self._buckets = [(0, self.flat.numel(), None)]
-        self._launch(0)
-        self._buckets = None
+        if self._buckets is None:               # discovery step: parameters that received nothing keep .grad = None
+            got = set(self._order)
+            for i, p in enumerate(self.params):
+                if i not in got:
+                    p.grad = None
 
     def describe(self):
         nb = len(self._buckets) if self._buckets else 0

@@ -60,7 +60,7 @@ def _worker(rank, world, port, out_dir):
         layouts.append((list(red.order), None if red._buckets is None else [(a, b) for a, b, _ in red._buckets]))
         torch.nn.utils.clip_grad_norm_(params, 1.0)
         opt.step()
-    views_ok = all(p.grad.data_ptr() == red.flat.data_ptr() + red.offsets[i][0] * 4 for i, p in enumerate(params))
+    views_ok = all(p.grad.data_ptr() == red.flat.data_ptr() + red.offsets[i][0] * 4 for i, p in enumerate(params))      # after finish(): .grad are the slots
 
     # a step that is not static: skip the last layers' gradient -> the check must raise
     raised = False
