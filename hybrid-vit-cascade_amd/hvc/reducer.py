@@ -73,6 +73,13 @@ class BucketedGradReducer:
         """After the discovery backward: lay the buffer out in arrival order, cut it into buckets, keep one hook per bucket.
         Parameters that received no gradient get no slot: their .grad stays None, as without any reducer."""
         seen = list(dict.fromkeys(self._order))
+        if self.world > 1:                      # every rank must cut the same buckets: compare the arrival orders once (fail loudly, not silently)
+            mine = torch.tensor(seen + [-1] * (len(self.params) - len(seen)), dtype=torch.int64, device=self.device)
+            lo, hi = mine.clone(), mine.clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.group)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.group)
+            if not torch.equal(lo, hi):
+                raise RuntimeError("BucketedGradReducer: the ranks' backward passes produced their gradients in different orders")
         for h in self._hooks:
             h.remove()
         self._hooks = []
