@@ -23,6 +23,10 @@ namespace {
 
 struct Pos { int b, d, h, w; };
 
+// n / d for n < 2^31 by a launch-time constant (hvc_kernels.h FastDiv): the flat-index decodes below otherwise cost two or three 64-bit
+// divisions (~100 instructions each) per 16-byte access, more than the interpolation itself
+__device__ __forceinline__ uint32_t fdiv32(uint32_t n, const FastDiv& f) { return (__umulhi(n, f.m) + n) >> f.l; }
+
 __device__ __forceinline__ Pos decode(int64_t m, int D, int H, int W) {
     Pos p;
     p.w = (int)(m % W); m /= W;
@@ -189,13 +193,21 @@ __global__ __launch_bounds__(256) void trilinear_fwd_kernel(const float* __restr
 // W % 4 == 0: one thread = four consecutive outputs of a row.  The index decode, the two outer axis maps and the four source row
 // bases are shared by the four outputs, which leave as one 16-byte store (the scalar kernel spends ~60 instructions and a 4-byte
 // store per element: instruction-bound at 0.7 TB/s of output on 16 x 256^3).  Same expression per element: bit-identical results.
+template <bool FAST>
 __global__ __launch_bounds__(256) void trilinear_fwd4_kernel(const float* __restrict__ src, float* __restrict__ dst,
-                                                              int B, int d, int h, int w, int D, int H, int W, int ac) {
+                                                              int B, int d, int h, int w, int D, int H, int W, int ac,
+                                                              FastDiv fW4, FastDiv fH, FastDiv fD) {
     const AxisMap md = axis_map(d, D, ac), mh = axis_map(h, H, ac), mw = axis_map(w, W, ac);
     const int W4 = W >> 2;
     const int64_t total = (int64_t)B * D * H * W4;
     for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
-        const Pos o = decode(idx, D, H, W4);      // o.w = group of four along W
+        Pos o;                                    // o.w = group of four along W
+        if constexpr (FAST) {                     // total < 2^31
+            const uint32_t q1 = fdiv32((uint32_t)idx, fW4), q2 = fdiv32(q1, fH), q3 = fdiv32(q2, fD);
+            o.w = (int)((uint32_t)idx - q1 * fW4.d); o.h = (int)(q1 - q2 * fH.d); o.d = (int)(q2 - q3 * fD.d); o.b = (int)q3;
+        } else {
+            o = decode(idx, D, H, W4);
+        }
         const float fd = md.src(o.d), fh = mh.src(o.h);
         const int d0 = min((int)fd, d - 1), h0 = min((int)fh, h - 1);
         const int d1 = min(d0 + 1, d - 1), h1 = min(h0 + 1, h - 1);
@@ -268,14 +280,22 @@ __global__ __launch_bounds__(256) void trilinear_bwd_kernel(const float* __restr
 
 // Adjoint of the 1-D interpolation along one axis of [outer][fine][inner] -> [outer][coarse][inner]; thread per output
 // element, inner fastest (coalesced); the ~2/r + 2 fine candidates of a coarse index are walked in a fixed order.
+template <bool FAST>
 __global__ __launch_bounds__(256) void axis_adjoint_kernel(const float* __restrict__ src, float* __restrict__ dst, int64_t outer, int fine,
-                                                            int coarse, int64_t inner, int ac) {
+                                                            int coarse, int64_t inner, int ac, FastDiv fInner, FastDiv fCoarse) {
     const AxisMap m = axis_map(coarse, fine, ac);
     const int64_t total = outer * coarse * inner;
     for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
-        const int64_t n = idx % inner;
-        const int i = (int)((idx / inner) % coarse);
-        const int64_t o = idx / (inner * coarse);
+        int64_t n, o;
+        int i;
+        if constexpr (FAST) {                     // total < 2^31
+            const uint32_t q1 = fdiv32((uint32_t)idx, fInner), q2 = fdiv32(q1, fCoarse);
+            n = (uint32_t)idx - q1 * fInner.d; i = (int)(q1 - q2 * fCoarse.d); o = q2;
+        } else {
+            n = idx % inner;
+            i = (int)((idx / inner) % coarse);
+            o = idx / (inner * coarse);
+        }
         int lo, hi;
         axis_range(i, m, fine, lo, hi);
         const float* s = src + (o * fine) * inner + n;
@@ -295,8 +315,9 @@ __global__ __launch_bounds__(256) void axis_adjoint_kernel(const float* __restri
 // the workgroup builds once in LDS (window start + 32 weights per coarse index) instead of ~12 instructions per candidate.  Same
 // candidates, same ascending order, same weights (axis_w) as axis_adjoint_kernel: bit-identical sums.  Round 3: 0.14 of the HBM roof.
 constexpr int kAdjMaxCoarse = 256, kAdjWin = 32;      // table: 32 KB of LDS
+template <bool FAST>
 __global__ __launch_bounds__(256) void axis_adjoint_w4_kernel(const float* __restrict__ src, float* __restrict__ dst, int64_t outer, int fine,
-                                                               int coarse, int ac) {
+                                                               int coarse, int ac, FastDiv fCoarse) {
     __shared__ __attribute__((aligned(16))) float wtab[kAdjMaxCoarse][kAdjWin];
     __shared__ int c0tab[kAdjMaxCoarse], hitab[kAdjMaxCoarse];
     const AxisMap m = axis_map(coarse, fine, ac);
@@ -316,8 +337,16 @@ __global__ __launch_bounds__(256) void axis_adjoint_w4_kernel(const float* __res
     __syncthreads();
     const int64_t total = outer * coarse;
     for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
-        const int i = (int)(idx % coarse);
-        const int64_t o = idx / coarse;
+        int i;
+        int64_t o;
+        if constexpr (FAST) {                     // total < 2^31
+            const uint32_t q = fdiv32((uint32_t)idx, fCoarse);
+            i = (int)((uint32_t)idx - q * fCoarse.d);
+            o = q;
+        } else {
+            i = (int)(idx % coarse);
+            o = idx / coarse;
+        }
         const int c0 = c0tab[i], hi = hitab[i];
         const float* s = src + o * fine + c0;
         float acc = 0.f;
@@ -375,8 +404,14 @@ hipError_t col2im_launch(const ConvGeom& g, const void* dcol, void* dsrc, int is
 hipError_t trilinear_launch(const float* src, float* dst, int B, int d, int h, int w, int D, int H, int W, bool align_corners, bool bwd,
                             hipStream_t st) {
     const int ac = align_corners ? 1 : 0;
-    if (!bwd && (W & 3) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15u) == 0)
-        hipLaunchKernelGGL(trilinear_fwd4_kernel, dim3(grid_for((int64_t)B * D * H * (W >> 2))), dim3(256), 0, st, src, dst, B, d, h, w, D, H, W, ac);
+    if (!bwd && (W & 3) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15u) == 0) {
+        const int64_t total = (int64_t)B * D * H * (W >> 2);
+        const FastDiv fW4 = make_fastdiv((uint32_t)(W >> 2)), fH = make_fastdiv((uint32_t)H), fD = make_fastdiv((uint32_t)D);
+        if (total < ((int64_t)1 << 31))
+            hipLaunchKernelGGL(trilinear_fwd4_kernel<true>, dim3(grid_for(total)), dim3(256), 0, st, src, dst, B, d, h, w, D, H, W, ac, fW4, fH, fD);
+        else
+            hipLaunchKernelGGL(trilinear_fwd4_kernel<false>, dim3(grid_for(total)), dim3(256), 0, st, src, dst, B, d, h, w, D, H, W, ac, fW4, fH, fD);
+    }
     else if (!bwd) hipLaunchKernelGGL(trilinear_fwd_kernel, dim3(grid_for((int64_t)B * D * H * W)), dim3(256), 0, st, src, dst, B, d, h, w, D, H, W, ac);
     else hipLaunchKernelGGL(trilinear_bwd_kernel, dim3(grid_for((int64_t)B * d * h * w * 64)), dim3(256), 0, st, src, dst, B, d, h, w, D, H, W, ac);
     return hipGetLastError();
@@ -392,12 +427,26 @@ hipError_t trilinear_bwd_separable_launch(const float* dout, float* dsrc, float*
     float* t1 = workspace;                                  // [B*D*H][w]
     float* t2 = workspace + (int64_t)B * D * H * w;         // [B*D][h][w]
     // window of a coarse index: at most 2 W / w + 4 fine candidates (axis_range) plus 3 of alignment
-    if ((W & 3) == 0 && (reinterpret_cast<uintptr_t>(dout) & 15u) == 0 && w <= kAdjMaxCoarse && 2 * ((W + w - 1) / w) + 7 <= kAdjWin)
-        hipLaunchKernelGGL(axis_adjoint_w4_kernel, dim3(grid_for((int64_t)B * D * H * w)), dim3(256), 0, st, dout, t1, (int64_t)B * D * H, W, w, ac);
-    else
-        hipLaunchKernelGGL(axis_adjoint_kernel, dim3(grid_for((int64_t)B * D * H * w)), dim3(256), 0, st, dout, t1, (int64_t)B * D * H, W, w, (int64_t)1, ac);
-    hipLaunchKernelGGL(axis_adjoint_kernel, dim3(grid_for((int64_t)B * D * h * w)), dim3(256), 0, st, t1, t2, (int64_t)B * D, H, h, (int64_t)w, ac);
-    hipLaunchKernelGGL(axis_adjoint_kernel, dim3(grid_for((int64_t)B * d * h * w)), dim3(256), 0, st, t2, dsrc, (int64_t)B, D, d, (int64_t)h * w, ac);
+    auto adjoint = [&](const float* in, float* out, int64_t outer, int fine, int coarse, int64_t inner) {
+        const int64_t total = outer * coarse * inner;
+        const FastDiv fi = make_fastdiv((uint32_t)inner), fc = make_fastdiv((uint32_t)coarse);
+        if (total < ((int64_t)1 << 31) && inner < ((int64_t)1 << 31))
+            hipLaunchKernelGGL(axis_adjoint_kernel<true>, dim3(grid_for(total)), dim3(256), 0, st, in, out, outer, fine, coarse, inner, ac, fi, fc);
+        else
+            hipLaunchKernelGGL(axis_adjoint_kernel<false>, dim3(grid_for(total)), dim3(256), 0, st, in, out, outer, fine, coarse, inner, ac, fi, fc);
+    };
+    if ((W & 3) == 0 && (reinterpret_cast<uintptr_t>(dout) & 15u) == 0 && w <= kAdjMaxCoarse && 2 * ((W + w - 1) / w) + 7 <= kAdjWin) {
+        const int64_t total = (int64_t)B * D * H * w;
+        const FastDiv fc = make_fastdiv((uint32_t)w);
+        if (total < ((int64_t)1 << 31))
+            hipLaunchKernelGGL(axis_adjoint_w4_kernel<true>, dim3(grid_for(total)), dim3(256), 0, st, dout, t1, (int64_t)B * D * H, W, w, ac, fc);
+        else
+            hipLaunchKernelGGL(axis_adjoint_w4_kernel<false>, dim3(grid_for(total)), dim3(256), 0, st, dout, t1, (int64_t)B * D * H, W, w, ac, fc);
+    } else {
+        adjoint(dout, t1, (int64_t)B * D * H, W, w, 1);
+    }
+    adjoint(t1, t2, (int64_t)B * D, H, h, w);
+    adjoint(t2, dsrc, (int64_t)B, D, d, (int64_t)h * w);
     return hipGetLastError();
 }
 
