@@ -1773,8 +1773,11 @@ hipError_t launch_bwd(const AttnArgs& a, hipStream_t st) {
         // 256-key workgroups of eight wavefronts once they fill every CU twice over (HVC_ATTN_BWD_WAVES=4 / 8 pins the form)
         constexpr bool CAN8 = sizeof(T) == 2 && VEC;
         const int pin = bwd_waves_pin();
-        // (d = 32: the four-wavefront form, three workgroups per CU - see LotTile - unless pinned)
-        const bool w8 = CAN8 && pin != 4 && (pin == 8 || (D != 32 && (int64_t)((a.Nk + 255) / 256) * a.B * a.H >= 512));
+        // (d = 32: the four-wavefront form, three workgroups per CU - see LotTile - unless pinned; few key blocks with the query range
+        // sliced (cross-attention): eight wavefronts, one workgroup per CU: -4.5 % same-box at d = 64 and d = 32)
+        const int qs_try = attention_bwd_qsplit(a.B, a.H, a.Nq, a.Nk);
+        const bool sliced = qs_try > 1 && a.dkv_partial && a.partial_floats >= (int64_t)2 * qs_try * a.B * a.H * a.Nk * D;
+        const bool w8 = CAN8 && pin != 4 && (pin == 8 || sliced || (D != 32 && (int64_t)((a.Nk + 255) / 256) * a.B * a.H >= 512));
         const int KBh = w8 ? 256 : kQB;
         const int nkb = (a.Nk + KBh - 1) / KBh;
         const size_t lds = dkv_lds_bytes<T, D>(DROP, w8 ? 8 : 4) + extra_lds();
