@@ -300,9 +300,17 @@ __global__ __launch_bounds__(256) void axis_adjoint_kernel(const float* __restri
         axis_range(i, m, fine, lo, hi);
         const float* s = src + (o * fine) * inner + n;
         float acc = 0.f;
-        for (int f = lo; f <= hi; ++f) {
-            const float wgt = axis_w(f, i, m, coarse);
-            if (wgt != 0.f) acc += wgt * s[(int64_t)f * inner];
+        for (int f0 = lo; f0 <= hi; f0 += 4) {            // four candidates at a time, loaded without a branch (clamped to the window's end: zero weight)
+            float v[4], wg[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int f = f0 + u;
+                v[u] = s[(int64_t)(f <= hi ? f : hi) * inner];
+                wg[u] = f <= hi ? axis_w(f, i, m, coarse) : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (wg[u] != 0.f) acc += wg[u] * v[u];
         }
         dst[idx] = acc;
     }
@@ -315,7 +323,7 @@ __global__ __launch_bounds__(256) void axis_adjoint_kernel(const float* __restri
 // the workgroup builds once in LDS (window start + 32 weights per coarse index) instead of ~12 instructions per candidate.  Same
 // candidates, same ascending order, same weights (axis_w) as axis_adjoint_kernel: bit-identical sums.  Round 3: 0.14 of the HBM roof.
 constexpr int kAdjMaxCoarse = 256, kAdjWin = 32;      // table: 32 KB of LDS
-template <bool FAST>
+template <bool FAST, int NC>      // NC = 16-byte chunks a window can span (3 / 4 / 6 / 8 for factors <= 2 / 4 / 8 / 12)
 __global__ __launch_bounds__(256) void axis_adjoint_w4_kernel(const float* __restrict__ src, float* __restrict__ dst, int64_t outer, int fine,
                                                                int coarse, int ac, FastDiv fCoarse) {
     __shared__ __attribute__((aligned(16))) float wtab[kAdjMaxCoarse][kAdjWin];
@@ -349,16 +357,19 @@ __global__ __launch_bounds__(256) void axis_adjoint_w4_kernel(const float* __res
         }
         const int c0 = c0tab[i], hi = hitab[i];
         const float* s = src + o * fine + c0;
+        // Every chunk of the window is LOADED without a branch (chunks past the window re-read chunk 0: valid memory, zero weights): with a
+        // branch around each load hipcc waits for the loads in flight at every join, and the eight loads of a thread went out one at a time
+        // (the W pass ran at 3.2 TB/s, latency-bound).
+        f32x4 q[NC];
+#pragma unroll
+        for (int cc = 0; cc < NC; ++cc) q[cc] = *reinterpret_cast<const f32x4*>(s + (c0 + 4 * cc <= hi ? 4 * cc : 0));
         float acc = 0.f;
 #pragma unroll
-        for (int cc = 0; cc < kAdjWin / 4; ++cc) {
-            if (c0 + 4 * cc <= hi) {
-                const f32x4 q = *reinterpret_cast<const f32x4*>(s + 4 * cc);
-                const f32x4 w = *reinterpret_cast<const f32x4*>(&wtab[i][4 * cc]);
+        for (int cc = 0; cc < NC; ++cc) {
+            const f32x4 w = *reinterpret_cast<const f32x4*>(&wtab[i][4 * cc]);
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (w[j] != 0.f) acc += w[j] * q[j];
-            }
+            for (int j = 0; j < 4; ++j)
+                if (w[j] != 0.f) acc += w[j] * q[cc][j];
         }
         dst[idx] = acc;
     }
@@ -438,10 +449,16 @@ hipError_t trilinear_bwd_separable_launch(const float* dout, float* dsrc, float*
     if ((W & 3) == 0 && (reinterpret_cast<uintptr_t>(dout) & 15u) == 0 && w <= kAdjMaxCoarse && 2 * ((W + w - 1) / w) + 7 <= kAdjWin) {
         const int64_t total = (int64_t)B * D * H * w;
         const FastDiv fc = make_fastdiv((uint32_t)w);
-        if (total < ((int64_t)1 << 31))
-            hipLaunchKernelGGL(axis_adjoint_w4_kernel<true>, dim3(grid_for(total)), dim3(256), 0, st, dout, t1, (int64_t)B * D * H, W, w, ac, fc);
-        else
-            hipLaunchKernelGGL(axis_adjoint_w4_kernel<false>, dim3(grid_for(total)), dim3(256), 0, st, dout, t1, (int64_t)B * D * H, W, w, ac, fc);
+        const int span = 2 * ((W + w - 1) / w) + 7;           // fine candidates of a coarse index + alignment (the launch condition above: <= 32)
+        const int nc = (span + 3) / 4;
+        const dim3 grid(grid_for(total));
+#define HVC_ADJ_W4(FASTV, NCV) hipLaunchKernelGGL((axis_adjoint_w4_kernel<FASTV, NCV>), grid, dim3(256), 0, st, dout, t1, (int64_t)B * D * H, W, w, ac, fc)
+        if (total < ((int64_t)1 << 31)) {
+            if (nc <= 3) HVC_ADJ_W4(true, 3); else if (nc <= 4) HVC_ADJ_W4(true, 4); else if (nc <= 6) HVC_ADJ_W4(true, 6); else HVC_ADJ_W4(true, 8);
+        } else {
+            HVC_ADJ_W4(false, 8);
+        }
+#undef HVC_ADJ_W4
     } else {
         adjoint(dout, t1, (int64_t)B * D * H, W, w, 1);
     }
