@@ -53,9 +53,8 @@ __device__ __forceinline__ void load_halo(const ConvC1Args& a, const TileId& id,
         const int hx = e % H::HXP, r = e / H::HXP, hy = r % H::HY, hz = r / H::HY;
         const int sz = sz0 + hz, sy = sy0 + hy, sx = sx0 + hx;
         const bool ok = sz >= 0 && sz < a.SD && sy >= 0 && sy < a.SH && sx >= 0 && sx < a.SW;
-        bf16 v = (bf16)0.f;
-        if (ok) v = xb[((int64_t)sz * a.SH + sy) * a.SW + sx];
-        halo[e] = v;
+        const bf16 v = xb[ok ? ((int64_t)sz * a.SH + sy) * a.SW + sx : 0];
+        halo[e] = ok ? v : (bf16)0.f;
     }
 }
 
@@ -180,8 +179,9 @@ __global__ __launch_bounds__(256) void conv_c1_dw_kernel(const ConvC1Args a) {
 #pragma unroll
             for (int k = 0; k < 2 * NT; ++k) {
                 const int c = lane + 64 * k, vox = c / (4 * NT), part = c % (4 * NT);
-                v[k] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-                if (in && id.x0 + vox < a.OW) v[k] = *reinterpret_cast<const bf16x8*>(drow + vox * a.Cout + part * 8);      // zeros past the end of the row
+                const bool ok = in && id.x0 + vox < a.OW;                    // zeros past the end of the row; the load itself carries no branch
+                const bf16x8 t = *reinterpret_cast<const bf16x8*>(drow + (ok ? vox * a.Cout + part * 8 : 0));
+                v[k] = ok ? t : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
             }
         };
         bf16x8 cur[2 * NT], nxt[2 * NT];
@@ -267,8 +267,8 @@ __global__ __launch_bounds__(512, 2) void conv_c1_dx_kernel(const ConvC1Args a) 
         const bf16* row = dyb + (((int64_t)(ok ? sz : 0) * a.OH + (ok ? sy : 0)) * a.OW + (ok ? sx : 0)) * CO + 8 * h;
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            v[s] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-            if (ok) v[s] = *reinterpret_cast<const bf16x8*>(row + 16 * s);
+            const bf16x8 t = *reinterpret_cast<const bf16x8*>(row + 16 * s);      // (row is a valid address either way: no branch around the load)
+            v[s] = ok ? t : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
         }
     };
     bf16x8 cur[KS], nxt[KS];
@@ -479,9 +479,12 @@ __global__ __launch_bounds__(256, 2) void conv3_halo_kernel(const Conv3Args a) {
             const int piece = e & 1, hv = e >> 1;
             const int hx = hv % kHX, q = hv / kHX, hy = q % kHY, hz = q / kHY;
             const int sz = z0 - 1 + hz, sy = y0 - 1 + hy, sx = x0 - 1 + hx;
-            hreg[it] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-            if (e < HN && sz >= 0 && sz < a.D && sy >= 0 && sy < a.H && sx >= 0 && sx < a.W)
-                hreg[it] = *reinterpret_cast<const bf16x8*>(xb + (((int64_t)sz * a.H + sy) * a.W + sx) * CI + 16 * ck + 8 * piece);
+            // loaded without a branch (out-of-volume pieces read the block's first voxel and are zeroed by a select): hipcc serialises loads
+            // that sit behind divergent branches
+            const bool ok = e < HN && sz >= 0 && sz < a.D && sy >= 0 && sy < a.H && sx >= 0 && sx < a.W;
+            const int64_t off = ok ? (((int64_t)sz * a.H + sy) * a.W + sx) * CI + 16 * ck + 8 * piece : 0;
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(xb + off);
+            hreg[it] = ok ? v : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
         }
     };
     auto halo_commit = [&](int first) {
